@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's `pkg/tracer` interface, backed by libgrt_hip.so.
+
+Same names, argument meaning and behaviour as the Go package so parity tests read like code
+written against the reference:
+
+    NewCamera(eye, lookat, vup, vfov, aspect)            camera.go:16
+    NewSphere(center, radius, mat) / NewAABB(min, max, mat)   sphere.go:17 / aabb.go:18
+    NormalMaterial / DiffuseMaterial / LambertMaterial / MetalicMaterial /
+    DielectricMaterial / LightMaterial                   material.go:15-41
+    NewScene(width, height, cam, objects, ...)           scene.go:35
+    Scene.Render(pixels, pitch, samples)                 scene.go:79
+
+The tested native host (C++) lives in host/tracer.hpp; this module is the ctypes route used
+by tests/ and bench.py.  Nothing here computes pixels: every call goes through the C ABI.
+"""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+
+from . import _capi
+from ._capi import (GRT_KIND_AABB, GRT_KIND_SPHERE, Camera, MaterialRec, Opts, PrimRec, SceneDesc,
+                    check, load)
+
+BIAS = 0.001  # scene.go:14
+MAX_DEPTH = 6  # scene.go:62
+
+
+# ---- materials (material.go:4-41) ---------------------------------------------------
+class Material:
+    __slots__ = ("Color", "RefrIndex", "Reflectivity", "Roughness", "Emittance", "Transparent",
+                 "Lambert", "Normal")
+
+    def __init__(self, color, refr_index, reflectivity, roughness, emittance, transparent, lambert,
+                 normal):
+        self.Color = tuple(float(c) for c in color)
+        self.RefrIndex = float(refr_index)
+        self.Reflectivity = float(reflectivity)
+        self.Roughness = float(roughness)
+        self.Emittance = float(emittance)
+        self.Transparent = bool(transparent)
+        self.Lambert = bool(lambert)
+        self.Normal = bool(normal)
+
+    def key(self):
+        return tuple(getattr(self, s) for s in self.__slots__)
+
+
+def NewColor(r, g, b):  # color.go:15
+    return (float(r), float(g), float(b))
+
+
+def NormalMaterial():  # material.go:15
+    return Material((0, 0, 0), 1, 0, 0, 0, False, False, True)
+
+
+def DiffuseMaterial(color):  # material.go:20
+    return Material(color, 1, 0, 0, 0, False, False, False)
+
+
+def LambertMaterial(albedo):  # material.go:25
+    return Material(albedo, 1, 0, 0, 0, False, True, False)
+
+
+def MetalicMaterial(albedo, reflectivity, roughness):  # material.go:30
+    return Material(albedo, 1, reflectivity, roughness, 0, False, False, False)
+
+
+def DielectricMaterial(index):  # material.go:35
+    return Material((0, 0, 0), index, 0, 0, 0, True, False, False)
+
+
+def LightMaterial(intensity, emittance):  # material.go:39
+    return Material(intensity, 1, 0, 0, emittance, False, False, False)
+
+
+# ---- primitives (sphere.go:10-19, aabb.go:10-21) ------------------------------------
+class Sphere:
+    def __init__(self, center, radius, mat):
+        self.Center = tuple(float(c) for c in center)
+        self.Radius = float(radius)
+        self.Mat = mat
+
+    def Material(self):
+        return self.Mat
+
+    def Pos(self):
+        return self.Center
+
+
+class AABB:
+    def __init__(self, mn, mx, mat):
+        self.MinBound = tuple(float(c) for c in mn)
+        self.MaxBound = tuple(float(c) for c in mx)
+        self.Center = tuple((a + b) * 0.5 for a, b in zip(self.MaxBound, self.MinBound))  # aabb.go:19
+        self.Mat = mat
+
+    def Material(self):
+        return self.Mat
+
+    def Pos(self):
+        return self.Center
+
+
+def NewSphere(center, radius, mat):
+    return Sphere(center, radius, mat)
+
+
+def NewAABB(mn, mx, mat):
+    return AABB(mn, mx, mat)
+
+
+# ---- camera (camera.go:16-30) -------------------------------------------------------
+def _sub(a, b):
+    return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
+
+
+def _scale(a, k):
+    return (a[0] * k, a[1] * k, a[2] * k)
+
+
+def _cross(a, b):
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+def _unit(a):
+    k = 1.0 / math.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+    return _scale(a, k)
+
+
+def NewCamera(eye, lookat, vup, vfov, aspect):
+    """Float64, operation order of camera.go:16-30 (host-side, once per scene)."""
+    theta = vfov * math.pi / 180
+    half_h = math.tan(theta / 2)
+    half_w = aspect * half_h
+    eye = tuple(float(c) for c in eye)
+    w = _unit(_sub(eye, lookat))
+    u = _unit(_cross(vup, w))
+    v = _unit(_cross(u, w))
+    cam = Camera()
+    cam.origin[:] = eye
+    cam.lower_left[:] = _sub(_sub(_sub(eye, _scale(u, half_w)), _scale(v, half_h)), w)
+    cam.horizontal[:] = _scale(u, 2 * half_w)
+    cam.vertical[:] = _scale(v, 2 * half_h)
+    return cam
+
+
+# ---- flattening: Scene.Objects []Hitable -> POD arrays ------------------------------
+def flatten(width, height, cam, objects, max_depth=MAX_DEPTH, bias=BIAS):
+    """The type switch the cgo shim performs: one grt_prim per object in
+    Scene.Objects order (the index is the object id), materials de-duplicated by value."""
+    mats, mat_index = [], {}
+    prims = (PrimRec * max(1, len(objects)))()
+    for i, o in enumerate(objects):
+        m = o.Material()
+        k = m.key()
+        if k not in mat_index:
+            mat_index[k] = len(mats)
+            mats.append(m)
+        p = prims[i]
+        p.material = mat_index[k]
+        if isinstance(o, Sphere):
+            p.kind = GRT_KIND_SPHERE
+            p.a[:] = o.Center
+            p.radius = o.Radius
+        elif isinstance(o, AABB):
+            p.kind = GRT_KIND_AABB
+            p.a[:] = o.MinBound
+            p.b[:] = o.MaxBound
+        else:  # e.g. tracer.List (list.go:6): no flat form
+            raise TypeError(f"object {i}: unsupported Hitable {type(o).__name__}")
+    mrec = (MaterialRec * max(1, len(mats)))()
+    for i, m in enumerate(mats):
+        r = mrec[i]
+        r.color[:] = m.Color
+        r.refr_index, r.reflectivity, r.roughness = m.RefrIndex, m.Reflectivity, m.Roughness
+        r.emittance = m.Emittance
+        r.transparent, r.lambert, r.normal = int(m.Transparent), int(m.Lambert), int(m.Normal)
+    desc = SceneDesc()
+    desc.width, desc.height, desc.max_depth, desc.bias = width, height, max_depth, bias
+    desc.cam = cam
+    return desc, prims, len(objects), mrec, len(mats)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """tracer.Scene (scene.go:17-27) staged on the GPU behind a grt_scene handle."""
+
+    def __init__(self, width, height, cam, objects, globalPmap=None, causticPmap=None,
+                 max_depth=MAX_DEPTH, bias=BIAS):
+        self.W, self.H, self.Cam, self.Objects = int(width), int(height), cam, list(objects)
+        self.globalPmap, self.causticPmap = globalPmap, causticPmap
+        self.maxDepth = max_depth
+        self.flat = flatten(self.W, self.H, cam, self.Objects, max_depth, bias)
+        self._lib = load()
+        h = C.c_void_p()
+        desc, prims, n_prims, mats, n_mats = self.flat
+        check(self._lib.grt_scene_create(C.byref(desc), prims, n_prims, mats, n_mats, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.grt_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    @staticmethod
+    def opts(seed=None, first_device=0, n_devices=1, chunk_spp=0):
+        o = Opts()
+        # the reference seeds with time.Now().Unix() (scene.go:114)
+        o.seed = int(time.time()) if seed is None else int(seed)
+        o.first_device, o.n_devices, o.chunk_spp, o.flags = first_device, n_devices, chunk_spp, 0
+        return o
+
+    # scene.go:79
+    def Render(self, pixels, pitch, samples, seed=None, **kw):
+        """pixels: writable buffer of H*pitch bytes (numpy uint8 / bytearray); B,G,R at
+        pixels[y*pitch + x*bpp + {0,1,2}], bpp = pitch // W."""
+        buf = np.frombuffer(pixels, dtype=np.uint8) if not isinstance(pixels, np.ndarray) else pixels
+        if buf.size < self.H * pitch:
+            raise ValueError("pixels buffer smaller than H*pitch")
+        o = self.opts(seed, **kw)
+        check(self._lib.grt_render(self.handle, C.byref(o), _ptr(buf), pitch, samples))
+
+    def RenderAccum(self, samples, seed=None, **kw):
+        """Linear RGB sums, float32 [H, W, 3] (what scene.go:96 accumulates)."""
+        out = np.empty((self.H, self.W, 3), np.float32)
+        o = self.opts(seed, **kw)
+        check(self._lib.grt_render_accum(self.handle, C.byref(o), _ptr(out), samples))
+        return out
+
+    def TraceSamples(self, pixel_xy, samples, seed=None):
+        xy = np.ascontiguousarray(pixel_xy, np.int32).reshape(-1, 2)
+        rgb = np.empty((xy.shape[0], samples, 3), np.float32)
+        nr = np.empty((xy.shape[0], samples), np.int32)
+        o = self.opts(seed)
+        check(self._lib.grt_trace_samples(self.handle, C.byref(o), _ptr(xy), xy.shape[0], samples,
+                                          _ptr(rgb), _ptr(nr)))
+        return rgb, nr
+
+    def PrimaryHits(self, jitter_mode=_capi.GRT_JITTER_CENTER, seed=1):
+        n = self.W * self.H
+        ids = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        fb = C.c_uint64(0)
+        o = self.opts(seed)
+        check(self._lib.grt_primary_hits(self.handle, C.byref(o), jitter_mode, _ptr(ids), _ptr(t),
+                                         _ptr(nrm), C.byref(fb)))
+        return ids.reshape(self.H, self.W), t.reshape(self.H, self.W), nrm.reshape(self.H, self.W, 3), fb.value
+
+    def last_ray_count(self):
+        return int(self._lib.grt_last_ray_count())
+
+    def last_kernel_ms(self):
+        return float(self._lib.grt_last_kernel_ms())
+
+
+def NewScene(width, height, cam, objects, globalPmap=None, causticPmap=None):  # scene.go:35
+    return Scene(width, height, cam, objects, globalPmap, causticPmap)

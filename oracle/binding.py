@@ -1,0 +1,126 @@
+"""ctypes binding of oracle/libgrt_oracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+It reuses the product's POD record definitions (the boundary is the same) but never the
+product's compute path.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrt_oracle.so")
+
+_pkg = importlib.import_module("go-raytracer_amd")
+_capi = _pkg._capi
+P = C.POINTER
+_vp = C.c_void_p
+_d3 = P(C.c_double)
+
+PROTOTYPES = {
+    "grto_rng_u01": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "grto_camera_new": (None, [_d3, _d3, _d3, C.c_double, C.c_double, P(_capi.Camera)]),
+    "grto_camera_ray": (None, [P(_capi.Camera), C.c_double, C.c_double, _d3, _d3]),
+    "grto_prim_hit": (C.c_double, [P(_capi.PrimRec), _d3, _d3, C.c_double, C.c_double]),
+    "grto_prim_surface": (None, [P(_capi.PrimRec), _d3, _d3]),
+    "grto_scene_create": (C.c_int, [P(_capi.SceneDesc), P(_capi.PrimRec), C.c_int32,
+                                    P(_capi.MaterialRec), C.c_int32, P(_vp)]),
+    "grto_scene_destroy": (None, [_vp]),
+    "grto_intersect": (C.c_int, [_vp, _d3, _d3, P(C.c_double)]),
+    "grto_reflect": (None, [_d3, _d3, _d3]),
+    "grto_refract": (C.c_int, [_d3, _d3, C.c_double, C.c_double, _d3]),
+    "grto_sample_hemisphere_normal": (None, [_d3, C.c_double, C.c_double, _d3]),
+    "grto_trace_samples": (C.c_int, [_vp, C.c_uint64, _vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "grto_write_color": (None, [_d3, _vp]),
+    "grto_render": (C.c_int, [_vp, C.c_uint64, _vp, C.c_int32, C.c_int32, C.c_int32]),
+    "grto_render_accum": (C.c_int, [_vp, C.c_uint64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "grto_primary_hits": (C.c_int, [_vp, C.c_uint64, C.c_int32, _vp, _vp, _vp]),
+    "grto_last_ray_count": (C.c_uint64, []),
+    "grto_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleScene:
+    """Float64 CPU restatement of tracer.Scene over the same flattened records."""
+
+    def __init__(self, flat):
+        self.lib = load()
+        self.flat = flat
+        desc, prims, n_prims, mats, n_mats = flat
+        self.W, self.H = desc.width, desc.height
+        h = _vp()
+        rc = self.lib.grto_scene_create(C.byref(desc), prims, n_prims, mats, n_mats, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"grto_scene_create failed: {rc}")
+        self.handle = h
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.grto_scene_destroy(self.handle)
+            self.handle = None
+
+    def Render(self, pixels, pitch, samples, seed=1, nthreads=0):
+        rc = self.lib.grto_render(self.handle, seed, _ptr(pixels), pitch, samples, nthreads)
+        assert rc == 0, rc
+
+    def RenderAccum(self, samples, seed=1, row_begin=0, row_end=None, nthreads=0):
+        out = np.zeros((self.H, self.W, 3), np.float64)
+        rc = self.lib.grto_render_accum(self.handle, seed, _ptr(out), samples, row_begin,
+                                        self.H if row_end is None else row_end, nthreads)
+        assert rc == 0, rc
+        return out
+
+    def TraceSamples(self, pixel_xy, samples, seed=1):
+        xy = np.ascontiguousarray(pixel_xy, np.int32).reshape(-1, 2)
+        rgb = np.empty((xy.shape[0], samples, 3), np.float64)
+        nr = np.empty((xy.shape[0], samples), np.int32)
+        rc = self.lib.grto_trace_samples(self.handle, seed, _ptr(xy), xy.shape[0], samples, _ptr(rgb), _ptr(nr))
+        assert rc == 0, rc
+        return rgb, nr
+
+    def PrimaryHits(self, jitter_mode=0, seed=1):
+        n = self.W * self.H
+        ids = np.empty(n, np.int32)
+        t = np.empty(n, np.float64)
+        nrm = np.empty((n, 3), np.float64)
+        rc = self.lib.grto_primary_hits(self.handle, seed, jitter_mode, _ptr(ids), _ptr(t), _ptr(nrm))
+        assert rc == 0, rc
+        return ids.reshape(self.H, self.W), t.reshape(self.H, self.W), nrm.reshape(self.H, self.W, 3)
+
+    def Intersect(self, orig, direction):
+        t = C.c_double(0)
+        i = self.lib.grto_intersect(self.handle, d3(orig), d3(direction), C.byref(t))
+        return i, t.value
+
+    def last_ray_count(self):
+        return int(self.lib.grto_last_ray_count())
