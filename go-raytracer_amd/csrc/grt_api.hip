@@ -1,0 +1,552 @@
+// grt_api.hip — the C ABI of include/grt.h over the kernels in grt_kernels.h.
+// gfx950 only; no torch types, no CPU fallback: every pixel comes out of a HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/grt.h"
+#include "grt_internal.h"
+#include "grt_kernels.h"
+
+#define GRT_API extern "C" __attribute__((visibility("default")))
+
+// ---- error channel ---------------------------------------------------------------------
+static thread_local std::string g_err;
+static thread_local uint64_t g_last_rays = 0;
+static thread_local double g_last_ms = 0.0;
+
+int grt_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+GRT_API const char* grt_last_error(void) { return g_err.c_str(); }
+GRT_API const char* grt_version(void) { return "grt-hip 0.1 (gfx950)"; }
+GRT_API uint64_t grt_last_ray_count(void) { return g_last_rays; }
+GRT_API double grt_last_kernel_ms(void) { return g_last_ms; }
+GRT_API int grt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+GRT_API double grt_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
+  return grt_rng_draw64(grt_rng_path_key(grt_rng_pixel_key(grt_rng_seed32(seed), pixel), sample), dim);
+}
+
+// ---- scene staging ---------------------------------------------------------------------
+struct DeviceScene {
+  float4* prims = nullptr;
+  float4* mats = nullptr;
+  float4* lights = nullptr;
+  double* prims64 = nullptr;
+};
+
+struct grt_scene {
+  grt_scene_desc d;
+  std::vector<grt_prim> prims;
+  std::vector<grt_material> mats;
+  std::vector<int> lights;    // scene.go:42-46
+  std::vector<int> tobjects;  // scene.go:48-50
+  double light_area = 0.0;
+  std::mutex mu;
+  std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
+};
+
+static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_prims, const grt_material* mats,
+                          int n_mats) {
+  if (!d) return grt_fail(GRT_EINVAL, "grt_scene_create: desc is NULL");
+  if (d->width <= 0 || d->height <= 0) return grt_fail(GRT_EINVAL, "grt_scene_create: bad size %dx%d", d->width, d->height);
+  if ((int64_t)d->width * d->height > (int64_t)1 << 28) return grt_fail(GRT_ELIMIT, "grt_scene_create: image above 2^28 pixels");
+  if (n_prims < 0 || n_mats < 0 || (n_prims && !prims) || (n_mats && !mats))
+    return grt_fail(GRT_EINVAL, "grt_scene_create: bad prim/material arrays");
+  if (n_prims > GRT_MAX_LINEAR_PRIMS)
+    return grt_fail(GRT_ELIMIT, "grt_scene_create: %d objects; the linear-scan kernels take at most %d", n_prims,
+                    GRT_MAX_LINEAR_PRIMS);
+  for (int i = 0; i < n_prims; ++i) {
+    if (prims[i].kind != GRT_KIND_SPHERE && prims[i].kind != GRT_KIND_AABB)
+      return grt_fail(GRT_EINVAL, "grt_scene_create: object %d has unknown kind %d", i, prims[i].kind);
+    if (prims[i].material < 0 || prims[i].material >= n_mats)
+      return grt_fail(GRT_EINVAL, "grt_scene_create: object %d material %d out of range", i, prims[i].material);
+  }
+  return GRT_OK;
+}
+
+GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, int32_t n_prims,
+                             const grt_material* mats, int32_t n_mats, grt_scene** out) {
+  if (!out) return grt_fail(GRT_EINVAL, "grt_scene_create: out is NULL");
+  int rc = validate_scene(desc, prims, n_prims, mats, n_mats);
+  if (rc) return rc;
+  grt_scene* s = new grt_scene;
+  s->d = *desc;
+  s->prims.assign(prims, prims + n_prims);
+  s->mats.assign(mats, mats + n_mats);
+  for (int i = 0; i < n_prims; ++i) {  // NewScene, scene.go:40-51
+    const grt_material& m = s->mats[s->prims[i].material];
+    if (m.emittance > 0) {
+      s->lights.push_back(i);
+      s->light_area += m.color[0] + m.color[1] + m.color[2];
+    }
+    if (m.transparent) s->tobjects.push_back(i);
+  }
+  *out = s;
+  return GRT_OK;
+}
+
+GRT_API void grt_scene_destroy(grt_scene* s) {
+  if (!s) return;
+  int cur = 0;
+  bool have = hipGetDevice(&cur) == hipSuccess;
+  for (auto& kv : s->dev) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    (void)hipFree(kv.second.prims);
+    (void)hipFree(kv.second.mats);
+    (void)hipFree(kv.second.lights);
+    (void)hipFree(kv.second.prims64);
+  }
+  if (have) (void)hipSetDevice(cur);
+  delete s;
+}
+
+const grt_scene_desc* grt_scene_desc_of(const grt_scene* s) { return &s->d; }
+
+// Stage the SoA copies on the current device (first use only).
+static int stage(grt_scene* s, DeviceScene& out) {
+  int dev = 0;
+  GRT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(s->mu);
+  auto it = s->dev.find(dev);
+  if (it != s->dev.end()) {
+    out = it->second;
+    return GRT_OK;
+  }
+  const size_t np = s->prims.size(), nm = s->mats.size(), nl = s->lights.size();
+  std::vector<float4> hp(2 * std::max<size_t>(np, 1)), hm(2 * std::max<size_t>(nm, 1)), hl(2 * std::max<size_t>(nl, 1));
+  std::vector<double> h64(8 * std::max<size_t>(np, 1));
+  for (size_t i = 0; i < np; ++i) {
+    const grt_prim& p = s->prims[i];
+    const grt_material& m = s->mats[p.material];
+    int bits = (p.kind == GRT_KIND_AABB ? 1 : 0) | (m.emittance > 0 ? 2 : 0) | (p.material << 8);
+    float w;
+    memcpy(&w, &bits, 4);
+    hp[2 * i] = make_float4((float)p.a[0], (float)p.a[1], (float)p.a[2], (float)p.radius);
+    if (p.kind == GRT_KIND_AABB)
+      hp[2 * i + 1] = make_float4((float)p.b[0], (float)p.b[1], (float)p.b[2], w);
+    else
+      hp[2 * i + 1] = make_float4((float)(p.radius * p.radius), 0.0f, 0.0f, w);
+    double* q = &h64[8 * i];
+    q[0] = p.a[0], q[1] = p.a[1], q[2] = p.a[2], q[3] = p.b[0], q[4] = p.b[1], q[5] = p.b[2];
+    q[6] = p.radius, q[7] = p.kind == GRT_KIND_AABB ? 1.0 : 0.0;
+  }
+  for (size_t i = 0; i < nm; ++i) {
+    const grt_material& m = s->mats[i];
+    int flags = (m.transparent ? GRT_MAT_TRANSPARENT : 0) | (m.lambert ? GRT_MAT_LAMBERT : 0) | (m.normal ? GRT_MAT_NORMAL : 0);
+    float w;
+    memcpy(&w, &flags, 4);
+    hm[2 * i] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], (float)m.refr_index);
+    hm[2 * i + 1] = make_float4((float)m.reflectivity, (float)m.roughness, (float)m.emittance, w);
+  }
+  for (size_t k = 0; k < nl; ++k) {
+    const grt_prim& p = s->prims[s->lights[k]];
+    double pos[3];
+    for (int c = 0; c < 3; ++c) pos[c] = p.kind == GRT_KIND_AABB ? (p.b[c] + p.a[c]) * 0.5 : p.a[c];  // aabb.go:19, sphere.go:52
+    const grt_material& m = s->mats[p.material];
+    hl[2 * k] = make_float4((float)pos[0], (float)pos[1], (float)pos[2], (float)s->lights[k]);
+    hl[2 * k + 1] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], 0.0f);
+  }
+  DeviceScene d;
+  GRT_HIP(hipMalloc(&d.prims, hp.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&d.mats, hm.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&d.lights, hl.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&d.prims64, h64.size() * sizeof(double)));
+  GRT_HIP(hipMemcpy(d.prims, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.mats, hm.data(), hm.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.lights, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.prims64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice));
+  s->dev[dev] = d;
+  out = d;
+  return GRT_OK;
+}
+
+int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
+  DeviceScene d;
+  int rc = stage(s, d);
+  if (rc) return rc;
+  const grt_camera& c = s->d.cam;
+  KScene k;
+  k.cam.ox = (float)c.origin[0], k.cam.oy = (float)c.origin[1], k.cam.oz = (float)c.origin[2];
+  k.cam.lx = (float)(c.lower_left[0] - c.origin[0]);
+  k.cam.ly = (float)(c.lower_left[1] - c.origin[1]);
+  k.cam.lz = (float)(c.lower_left[2] - c.origin[2]);
+  k.cam.hx = (float)c.horizontal[0], k.cam.hy = (float)c.horizontal[1], k.cam.hz = (float)c.horizontal[2];
+  k.cam.vx = (float)c.vertical[0], k.cam.vy = (float)c.vertical[1], k.cam.vz = (float)c.vertical[2];
+  k.W = s->d.width, k.H = s->d.height, k.max_depth = s->d.max_depth, k.n_prims = (int)s->prims.size();
+  k.bias = (float)s->d.bias;
+  k.seed32 = grt_rng_seed32(seed);
+  k.n_lights = (int)s->lights.size();
+  k._pad = 0;
+  k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
+  *ks = k;
+  return GRT_OK;
+}
+
+static int kernel_view64(grt_scene* s, KScene64* k64) {
+  DeviceScene d;
+  int rc = stage(s, d);
+  if (rc) return rc;
+  const grt_camera& c = s->d.cam;
+  for (int i = 0; i < 3; ++i) {
+    k64->cam[i] = c.origin[i];
+    k64->cam[3 + i] = c.lower_left[i];
+    k64->cam[6 + i] = c.horizontal[i];
+    k64->cam[9 + i] = c.vertical[i];
+  }
+  k64->bias = s->d.bias;
+  k64->prims = d.prims64;
+  return GRT_OK;
+}
+
+// ---- work decomposition ----------------------------------------------------------------
+GRT_API int32_t grt_shard_rows(int32_t height, int32_t shard, int32_t n_shards) {
+  if (height <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return 0;
+  const int bands = (height + GRT_BAND_ROWS - 1) / GRT_BAND_ROWS;
+  int rows = 0;
+  for (int b = shard; b < bands; b += n_shards) rows += std::min(GRT_BAND_ROWS, height - b * GRT_BAND_ROWS);
+  return rows;
+}
+
+static int default_chunk_spp(int n_tiles, int samples) {
+  // Enough (tile, chunk) wave-items that the tail of the grid is short next to its body:
+  // ~16 items per wave slot (256 CUs x 32 waves), but no item shorter than 8 samples.
+  const int64_t want_items = 16 * 8192;
+  int64_t n_chunks = std::max<int64_t>(1, want_items / std::max(1, n_tiles));
+  int chunk = (int)((samples + n_chunks - 1) / n_chunks);
+  return std::min(samples, std::max(8, chunk));
+}
+
+static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shards, int samples, RenderJob* j) {
+  if (n_shards <= 0 || shard < 0 || shard >= n_shards) return grt_fail(GRT_EINVAL, "bad shard %d of %d", shard, n_shards);
+  if (samples <= 0) return grt_fail(GRT_EINVAL, "samples must be positive (got %d)", samples);
+  const int bands = (s->d.height + GRT_BAND_ROWS - 1) / GRT_BAND_ROWS;
+  const int local_bands = shard < bands ? (bands - shard + n_shards - 1) / n_shards : 0;
+  j->shard = shard, j->n_shards = n_shards;
+  j->rows_local = grt_shard_rows(s->d.height, shard, n_shards);
+  j->tiles_x = (s->d.width + 7) / 8;
+  j->n_tiles = j->tiles_x * local_bands;
+  j->chunk_spp = (o && o->chunk_spp > 0) ? std::min(o->chunk_spp, samples) : default_chunk_spp(j->n_tiles, samples);
+  j->n_chunks = (samples + j->chunk_spp - 1) / j->chunk_spp;
+  j->spp = samples;
+  return GRT_OK;
+}
+
+GRT_API uint64_t grt_accum_workspace_bytes(const grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards,
+                                           int32_t samples) {
+  RenderJob j;
+  if (!s || make_job(s, o, shard, n_shards, samples, &j)) return 0;
+  if (j.n_chunks <= 1) return 0;
+  return (uint64_t)j.n_chunks * (uint64_t)j.rows_local * (uint64_t)s->d.width * 3u * sizeof(float);
+}
+
+GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
+                                 float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count,
+                                 void* stream) {
+  if (!s || !d_rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_dev: NULL scene or output");
+  RenderJob j;
+  int rc = make_job(s, o, shard, n_shards, samples, &j);
+  if (rc) return rc;
+  if (j.rows_local == 0) return GRT_OK;
+  const uint64_t need = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
+  if (need > workspace_bytes || (need && !d_workspace))
+    return grt_fail(GRT_EINVAL, "grt_render_accum_dev: workspace %llu bytes, need %llu", (unsigned long long)workspace_bytes,
+                    (unsigned long long)need);
+  KScene ks;
+  rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t items = (int64_t)j.n_tiles * j.n_chunks;
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  float* target = j.n_chunks > 1 ? (float*)d_workspace : d_rgb_sum;
+  hipLaunchKernelGGL(k_pathtrace, dim3(grid), dim3(256), 0, st, ks, j, target, (unsigned long long*)d_ray_count);
+  GRT_HIP(hipGetLastError());
+  if (j.n_chunks > 1) {
+    const size_t n = (size_t)j.rows_local * (size_t)s->d.width * 3;
+    const unsigned g2 = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_sum_chunks, dim3(g2), dim3(256), 0, st, (const float*)d_workspace, j.n_chunks, n, d_rgb_sum);
+    GRT_HIP(hipGetLastError());
+  }
+  return GRT_OK;
+}
+
+GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows, int32_t samples, uint8_t* d_bgrx,
+                            int32_t pitch, void* stream) {
+  if (!d_rgb_sum || !d_bgrx || width <= 0 || rows < 0 || samples <= 0) return grt_fail(GRT_EINVAL, "grt_tonemap_dev: bad argument");
+  const int bpp = pitch / width;  // scene.go:85
+  if (bpp < 3) return grt_fail(GRT_EINVAL, "grt_tonemap_dev: pitch %d gives %d bytes per pixel (<3)", pitch, bpp);
+  if (rows == 0) return GRT_OK;
+  const size_t n = (size_t)width * rows;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_tonemap, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_rgb_sum, width, rows,
+                     1.0f / (float)samples, d_bgrx, pitch, bpp);
+  GRT_HIP(hipGetLastError());
+  return GRT_OK;
+}
+
+// ---- host-buffer entry points ------------------------------------------------------------
+struct ShardResult {
+  int rc = GRT_OK;
+  std::string err;
+  uint64_t rays = 0;
+  float ms = 0.0f;
+};
+
+// Renders one shard on `device` and scatters its rows into the caller's host buffers.
+static void render_shard_host(grt_scene* s, const grt_opts* o, int device, int shard, int n_shards, int samples,
+                              float* rgb_sum, uint8_t* pixels, int pitch, ShardResult* res) {
+  auto fail = [&](int rc) {
+    res->rc = rc;
+    res->err = g_err;
+  };
+  if (hipSetDevice(device) != hipSuccess) return fail(grt_fail(GRT_ENODEV, "hipSetDevice(%d) failed", device));
+  const int W = s->d.width, H = s->d.height;
+  const int rows = grt_shard_rows(H, shard, n_shards);
+  if (rows == 0) return;
+  const size_t nfl = (size_t)rows * W * 3;
+  const uint64_t ws_bytes = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
+  float* d_sum = nullptr;
+  void* d_ws = nullptr;
+  uint64_t* d_rays = nullptr;
+  uint8_t* d_bgr = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = GRT_OK;
+  auto H_ = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == GRT_OK) rc = grt_fail(GRT_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return e == hipSuccess;
+  };
+  std::vector<float> h_sum;
+  std::vector<uint8_t> h_bgr;
+  do {
+    if (!H_(hipMalloc(&d_sum, nfl * sizeof(float)), "hipMalloc(accum)")) break;
+    if (ws_bytes && !H_(hipMalloc(&d_ws, ws_bytes), "hipMalloc(workspace)")) break;
+    if (!H_(hipMalloc(&d_rays, sizeof(uint64_t)), "hipMalloc(ray counter)")) break;
+    if (!H_(hipMemsetAsync(d_rays, 0, sizeof(uint64_t), nullptr), "hipMemsetAsync")) break;
+    if (!H_(hipEventCreate(&e0), "hipEventCreate") || !H_(hipEventCreate(&e1), "hipEventCreate")) break;
+    H_(hipEventRecord(e0, nullptr), "hipEventRecord");
+    rc = grt_render_accum_dev(s, o, shard, n_shards, samples, d_sum, d_ws, ws_bytes, d_rays, nullptr);
+    if (rc) break;
+    H_(hipEventRecord(e1, nullptr), "hipEventRecord");
+    if (pixels) {
+      if (!H_(hipMalloc(&d_bgr, (size_t)rows * W * 3), "hipMalloc(bgr)")) break;
+      rc = grt_tonemap_dev(d_sum, W, rows, samples, d_bgr, W * 3, nullptr);
+      if (rc) break;
+      h_bgr.resize((size_t)rows * W * 3);
+      if (!H_(hipMemcpy(h_bgr.data(), d_bgr, h_bgr.size(), hipMemcpyDeviceToHost), "hipMemcpy(bgr)")) break;
+    }
+    if (rgb_sum) {
+      h_sum.resize(nfl);
+      if (!H_(hipMemcpy(h_sum.data(), d_sum, nfl * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(accum)")) break;
+    }
+    if (!H_(hipMemcpy(&res->rays, d_rays, sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(rays)")) break;
+    if (!H_(hipEventSynchronize(e1), "hipEventSynchronize")) break;
+    H_(hipEventElapsedTime(&res->ms, e0, e1), "hipEventElapsedTime");
+  } while (0);
+  if (rc == GRT_OK) {
+    // scatter the packed bands to their rows (the collector of scene.go:123-132)
+    const int bpp = pixels ? pitch / W : 0;
+    int lrow = 0;
+    const int bands = (H + GRT_BAND_ROWS - 1) / GRT_BAND_ROWS;
+    for (int b = shard; b < bands; b += n_shards)
+      for (int y = b * GRT_BAND_ROWS; y < std::min(H, (b + 1) * GRT_BAND_ROWS); ++y, ++lrow) {
+        if (rgb_sum) memcpy(rgb_sum + (size_t)y * W * 3, h_sum.data() + (size_t)lrow * W * 3, (size_t)W * 3 * sizeof(float));
+        if (pixels) {
+          const uint8_t* src = h_bgr.data() + (size_t)lrow * W * 3;
+          uint8_t* dst = pixels + (size_t)y * pitch;
+          for (int x = 0; x < W; ++x) {  // bytes beyond B,G,R stay untouched (scene.go:71-73)
+            dst[(size_t)x * bpp + 0] = src[3 * x + 0];
+            dst[(size_t)x * bpp + 1] = src[3 * x + 1];
+            dst[(size_t)x * bpp + 2] = src[3 * x + 2];
+          }
+        }
+      }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_sum);
+  (void)hipFree(d_ws);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_bgr);
+  if (rc) fail(rc);
+}
+
+static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_sum, uint8_t* pixels, int pitch) {
+  grt_opts opts = o ? *o : grt_opts{0, 0, 1, 0, 0};
+  const int G = std::max(1, opts.n_devices);
+  const int ndev = grt_device_count();
+  if (ndev <= 0) return grt_fail(GRT_ENODEV, "no HIP device visible");
+  if (opts.first_device < 0 || opts.first_device + G > ndev)
+    return grt_fail(GRT_ENODEV, "devices %d..%d requested, %d visible", opts.first_device, opts.first_device + G - 1, ndev);
+  if (samples <= 0) return grt_fail(GRT_EINVAL, "samples must be positive (got %d)", samples);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  std::vector<ShardResult> res(G);
+  if (G == 1) {
+    render_shard_host(s, &opts, opts.first_device, 0, 1, samples, rgb_sum, pixels, pitch, &res[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+      th.emplace_back(render_shard_host, s, &opts, opts.first_device + g, g, G, samples, rgb_sum, pixels, pitch, &res[g]);
+    for (auto& t : th) t.join();
+  }
+  (void)hipSetDevice(cur);
+  g_last_rays = 0;
+  g_last_ms = 0.0;
+  for (int g = 0; g < G; ++g) {
+    if (res[g].rc) {
+      g_err = res[g].err;
+      return res[g].rc;
+    }
+    g_last_rays += res[g].rays;
+    g_last_ms = std::max(g_last_ms, (double)res[g].ms);
+  }
+  return GRT_OK;
+}
+
+GRT_API int grt_render(grt_scene* s, const grt_opts* o, uint8_t* pixels, int32_t pitch, int32_t samples) {
+  if (!s || !pixels) return grt_fail(GRT_EINVAL, "grt_render: NULL scene or pixels");
+  if (pitch / s->d.width < 3) return grt_fail(GRT_EINVAL, "grt_render: pitch %d gives %d bytes per pixel (<3)", pitch, pitch / s->d.width);
+  return render_host(s, o, samples, nullptr, pixels, pitch);
+}
+
+GRT_API int grt_render_accum(grt_scene* s, const grt_opts* o, float* rgb_sum, int32_t samples) {
+  if (!s || !rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum: NULL scene or output");
+  return render_host(s, o, samples, rgb_sum, nullptr, 0);
+}
+
+static int use_device(const grt_opts* o) {
+  const int dev = o ? o->first_device : 0;
+  const int ndev = grt_device_count();
+  if (ndev <= 0) return grt_fail(GRT_ENODEV, "no HIP device visible");
+  if (dev < 0 || dev >= ndev) return grt_fail(GRT_ENODEV, "device %d requested, %d visible", dev, ndev);
+  GRT_HIP(hipSetDevice(dev));
+  return GRT_OK;
+}
+
+GRT_API int grt_trace_samples(grt_scene* s, const grt_opts* o, const int32_t* pixel_xy, int32_t n_pixels, int32_t samples,
+                              float* rgb, int32_t* n_rays) {
+  if (!s || !pixel_xy || !rgb || n_pixels < 0 || samples < 0) return grt_fail(GRT_EINVAL, "grt_trace_samples: bad argument");
+  for (int i = 0; i < n_pixels; ++i)
+    if (pixel_xy[2 * i] < 0 || pixel_xy[2 * i] >= s->d.width || pixel_xy[2 * i + 1] < 0 || pixel_xy[2 * i + 1] >= s->d.height)
+      return grt_fail(GRT_EINVAL, "grt_trace_samples: pixel %d outside the image", i);
+  const size_t n = (size_t)n_pixels * samples;
+  if (n == 0) return GRT_OK;
+  int rc = use_device(o);
+  if (rc) return rc;
+  KScene ks;
+  rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  int* d_xy = nullptr;
+  float* d_rgb = nullptr;
+  int* d_nr = nullptr;
+  rc = GRT_OK;
+  do {
+#define TRY(x)                                                               \
+  {                                                                          \
+    hipError_t e_ = (x);                                                     \
+    if (e_ != hipSuccess) {                                                  \
+      rc = grt_fail(GRT_EHIP, "%s: %s", #x, hipGetErrorString(e_));          \
+      break;                                                                 \
+    }                                                                        \
+  }
+    TRY(hipMalloc(&d_xy, (size_t)n_pixels * 2 * sizeof(int)));
+    TRY(hipMalloc(&d_rgb, n * 3 * sizeof(float)));
+    TRY(hipMalloc(&d_nr, n * sizeof(int)));
+    TRY(hipMemcpy(d_xy, pixel_xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, ks, d_xy, n_pixels, samples,
+                       d_rgb, d_nr);
+    TRY(hipGetLastError());
+    TRY(hipMemcpy(rgb, d_rgb, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n_rays) TRY(hipMemcpy(n_rays, d_nr, n * sizeof(int), hipMemcpyDeviceToHost));
+  } while (0);
+  (void)hipFree(d_xy);
+  (void)hipFree(d_rgb);
+  (void)hipFree(d_nr);
+  return rc;
+}
+
+// flags bit 8..9 of opts->flags select the debug mode of the parity kernel:
+// 0 = FP32 + FP64 re-test of ambiguous lanes (default), 1 = FP32 only, 2 = FP64 only.
+GRT_API int grt_primary_hits(grt_scene* s, const grt_opts* o, int32_t jitter_mode, int32_t* id, float* t, float* normal_xyz,
+                             uint64_t* fallback_lanes) {
+  if (!s || !id || !t || !normal_xyz) return grt_fail(GRT_EINVAL, "grt_primary_hits: NULL argument");
+  if (jitter_mode != GRT_JITTER_CENTER && jitter_mode != GRT_JITTER_RNG)
+    return grt_fail(GRT_EINVAL, "grt_primary_hits: unknown jitter mode %d", jitter_mode);
+  int rc = use_device(o);
+  if (rc) return rc;
+  KScene ks;
+  KScene64 k64;
+  rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  rc = kernel_view64(s, &k64);
+  if (rc) return rc;
+  const size_t n = (size_t)ks.W * ks.H;
+  const int force = o ? (o->flags >> 8) & 3 : 0;
+  int* d_id = nullptr;
+  float* d_t = nullptr;
+  float* d_n = nullptr;
+  unsigned long long* d_fb = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  rc = GRT_OK;
+  do {
+    TRY(hipMalloc(&d_id, n * sizeof(int)));
+    TRY(hipMalloc(&d_t, n * sizeof(float)));
+    TRY(hipMalloc(&d_n, n * 3 * sizeof(float)));
+    TRY(hipMalloc(&d_fb, sizeof(unsigned long long)));
+    TRY(hipMemset(d_fb, 0, sizeof(unsigned long long)));
+    TRY(hipEventCreate(&e0));
+    TRY(hipEventCreate(&e1));
+    TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_primary_hits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, ks, k64, jitter_mode, d_id, d_t,
+                       d_n, d_fb, force);
+    TRY(hipGetLastError());
+    TRY(hipEventRecord(e1, nullptr));
+    TRY(hipMemcpy(id, d_id, n * sizeof(int), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(normal_xyz, d_n, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    unsigned long long fb = 0;
+    TRY(hipMemcpy(&fb, d_fb, sizeof fb, hipMemcpyDeviceToHost));
+    if (fallback_lanes) *fallback_lanes = fb;
+    float ms = 0;
+    TRY(hipEventElapsedTime(&ms, e0, e1));
+    g_last_ms = ms;
+    g_last_rays = n;
+  } while (0);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_id);
+  (void)hipFree(d_t);
+  (void)hipFree(d_n);
+  (void)hipFree(d_fb);
+  return rc;
+}
+
+GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t samples, uint32_t* d_checksum, void* stream) {
+  if (!s || !d_checksum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_primary_sweep_dev: bad argument");
+  KScene ks;
+  int rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  const int tiles = ((ks.W + 7) / 8) * ((ks.H + 7) / 8);
+  hipLaunchKernelGGL(k_primary_sweep, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
+                     d_checksum);
+  GRT_HIP(hipGetLastError());
+  return GRT_OK;
+}

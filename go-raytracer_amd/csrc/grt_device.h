@@ -1,0 +1,583 @@
+// grt_device.h — device-side scene layout and the per-ray device functions (gfx950 only).
+//
+// What each function restates (reference paths relative to the upstream repo):
+//   make_primary      Camera.Ray                       pkg/tracer/camera.go:34-39
+//   aabb_hit32        AABB.Hit                         pkg/tracer/aabb.go:25-45
+//   sphere_hit32      Sphere.Hit                       pkg/tracer/sphere.go:23-46
+//   intersect32       Scene.intersect                  pkg/tracer/scene.go:169-181
+//   surface32         Sphere.Surface / AABB.Surface    sphere.go:56-58 / aabb.go:55-72
+//   sample_hemi32     geom.SampleHemisphereNormal      pkg/geom/vec3.go:202-218
+//   reflect32/refract32  Vec3.Reflect / Vec3.Refract   vec3.go:129-131 / 134-159
+//   path_step         one level of Scene.trace         scene.go:237-349
+//   *64               the same in float64 with the reference's operation order (no FMA
+//                     contraction), used to re-test lanes whose FP32 decision margin is small
+//
+// FP32 formulation notes (decisions equal the reference's away from ties; ties are caught by
+// ambiguous32 and re-tested in FP64 by the parity kernel):
+//   - slabs are evaluated as fma(bound, 1/D, -O/D): 6 FMA per box instead of 6 sub + 6 div;
+//     a wave whose rays have a zero direction component takes the CAREFUL path that keeps
+//     the reference's (bound-O)/D form and Go's NaN/Inf rules for math.Min/Max;
+//   - the sphere discriminant uses l = oc - (oc.D/|D|^2) D, disc/|D|^2 = R^2 - |l|^2, which
+//     does not cancel catastrophically for distant origins (the naive halfB^2 - a*c loses
+//     ~3 digits at |oc| ~ 1000);
+//   - AABB.Surface's epsilon cascade is evaluated on a hit point whose entry-axis coordinate
+//     is snapped to the face (in float64 it lies within 1e-13 of it; in FP32 the 1e-4
+//     epsilon is the size of an ulp at 555 and the literal cascade would misfire).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grt_rng.h"
+
+#define GRT_DEV __device__ __forceinline__
+
+struct f3 {
+  float x, y, z;
+};
+GRT_DEV f3 mk3(float x, float y, float z) {
+  f3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+GRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+GRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+GRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+GRT_DEV f3 operator*(f3 a, float k) { return mk3(a.x * k, a.y * k, a.z * k); }
+GRT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+GRT_DEV float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+GRT_DEV f3 cross3(f3 a, f3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+GRT_DEV f3 fma3(f3 a, float k, f3 c) { return mk3(fmaf(a.x, k, c.x), fmaf(a.y, k, c.y), fmaf(a.z, k, c.z)); }
+GRT_DEV float rcp32(float x) { return __builtin_amdgcn_rcpf(x); }
+GRT_DEV float rsq32(float x) { return __builtin_amdgcn_rsqf(x); }
+GRT_DEV float sqrt32(float x) { return __builtin_amdgcn_sqrtf(x); }
+GRT_DEV f3 unit3(f3 a) { return a * rsq32(dot3(a, a)); }
+GRT_DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+// ---- scene as the kernels see it -----------------------------------------------------
+// prims[2i]   = (a.x, a.y, a.z, radius)          sphere centre | box MinBound
+// prims[2i+1] = (b.x, b.y, b.z, bits)            box MaxBound  | sphere: b.x = radius^2
+//               bits (int): bit0 kind (1 = AABB), bit1 emissive (Emittance > 0), mat << 8
+// mats[2m]    = (r, g, b, refr_index)
+// mats[2m+1]  = (reflectivity, roughness, emittance, flags)   flags: 1 transparent,
+//               2 lambert, 4 normal
+// lights[2k]  = (Pos().xyz, prim index), lights[2k+1] = (Color.rgb, 0)   scene.go:42-46
+struct KCamera {
+  float ox, oy, oz;  // origin
+  float lx, ly, lz;  // lowerLeft - origin (folded on the host in float64)
+  float hx, hy, hz;  // horizontal
+  float vx, vy, vz;  // vertical
+};
+struct KScene {
+  KCamera cam;
+  int W, H, max_depth, n_prims;
+  float bias;
+  uint32_t seed32;
+  int n_lights, _pad;
+  const float4* __restrict__ prims;
+  const float4* __restrict__ mats;
+  const float4* __restrict__ lights;
+};
+
+#define GRT_MAT_TRANSPARENT 1
+#define GRT_MAT_LAMBERT 2
+#define GRT_MAT_NORMAL 4
+
+struct Ray32 {
+  f3 O, D, invD, OinvD;
+  float a, inva;  // |D|^2 and its reciprocal
+};
+GRT_DEV void ray_setup(Ray32& r, f3 O, f3 D) {
+  r.O = O;
+  r.D = D;
+  r.invD = mk3(rcp32(D.x), rcp32(D.y), rcp32(D.z));
+  r.OinvD = O * r.invD;
+  r.a = dot3(D, D);
+  r.inva = rcp32(r.a);
+}
+GRT_DEV bool ray_has_zero(const Ray32& r) { return (r.D.x == 0.0f) | (r.D.y == 0.0f) | (r.D.z == 0.0f); }
+
+// Camera.Ray (camera.go:34-39): D = lowerLeft + horizontal*u + vertical*v - origin, unnormalised.
+GRT_DEV void make_primary(const KScene& S, int x, int y, float ju, float jv, f3& O, f3& D) {
+  float u = ((float)x + ju) * (1.0f / (float)S.W);
+  float v = ((float)y + jv) * (1.0f / (float)S.H);
+  O = mk3(S.cam.ox, S.cam.oy, S.cam.oz);
+  D = mk3(fmaf(S.cam.vx, v, fmaf(S.cam.hx, u, S.cam.lx)), fmaf(S.cam.vy, v, fmaf(S.cam.hy, u, S.cam.ly)),
+          fmaf(S.cam.vz, v, fmaf(S.cam.hz, u, S.cam.lz)));
+}
+
+// Go math.Min/Max in FP32 (vec3.go:104-111): +-Inf beats NaN, else NaN propagates.
+GRT_DEV float gomax32(float x, float y) {
+  if ((x == INFINITY) | (y == INFINITY)) return INFINITY;
+  if ((x != x) | (y != y)) return NAN;
+  return x > y ? x : y;
+}
+GRT_DEV float gomin32(float x, float y) {
+  if ((x == -INFINITY) | (y == -INFINITY)) return -INFINITY;
+  if ((x != x) | (y != y)) return NAN;
+  return x < y ? x : y;
+}
+
+template <bool CAREFUL>
+GRT_DEV float aabb_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, float tmax) {
+  if (!CAREFUL) {
+    float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
+    float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
+    float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
+    float t0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float t1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    float lo = fmaxf(tmin, t0), hi = fminf(tmax, t1);
+    return hi > lo ? t0 : -1.0f;  // aabb.go:41-44: returns the ENTRY distance t0
+  } else {
+    float x0 = (pa.x - r.O.x) * r.invD.x, x1 = (pb.x - r.O.x) * r.invD.x;
+    float y0 = (pa.y - r.O.y) * r.invD.y, y1 = (pb.y - r.O.y) * r.invD.y;
+    float z0 = (pa.z - r.O.z) * r.invD.z, z1 = (pb.z - r.O.z) * r.invD.z;
+    float t0 = gomax32(gomax32(gomin32(x0, x1), gomin32(y0, y1)), gomin32(z0, z1));
+    float t1 = gomin32(gomin32(gomax32(x0, x1), gomax32(y0, y1)), gomax32(z0, z1));
+    float lo = tmin, hi = tmax;
+    if (t0 > lo) lo = t0;
+    if (t1 < hi) hi = t1;
+    if (hi <= lo) return -1.0f;
+    return t0;
+  }
+}
+
+GRT_DEV float sphere_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, float tmax) {
+  f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
+  float k = dot3(oc, r.D) * r.inva;   // halfB / a
+  f3 l = fma3(r.D, -k, oc);           // component of oc perpendicular to D
+  float s2 = (pb.x - dot3(l, l)) * r.inva;  // disc / a^2
+  float sq = sqrt32(s2);              // NaN when disc < 0: both window tests then fail
+  float t1 = -k - sq, t2 = -k + sq;
+  float t = ((t2 > tmin) & (t2 < tmax)) ? t2 : -1.0f;
+  return ((t1 > tmin) & (t1 < tmax)) ? t1 : t;
+}
+
+// Scene.intersect (scene.go:169-181): nearest hit over all objects in order, tMax shrinking,
+// a candidate accepted when ht > 0.  Returns the object index or -1.
+template <bool CAREFUL>
+GRT_DEV int intersect32_t(const KScene& S, const Ray32& r, float& t_out) {
+  float tbest = 3.402823466e38f;
+  int best = -1;
+  for (int i = 0; i < S.n_prims; ++i) {
+    float4 pa = S.prims[2 * i], pb = S.prims[2 * i + 1];
+    float ht;
+    if (__float_as_int(pb.w) & 1)
+      ht = aabb_hit32<CAREFUL>(pa, pb, r, S.bias, tbest);
+    else
+      ht = sphere_hit32(pa, pb, r, S.bias, tbest);
+    if (ht > 0.0f) {
+      best = i;
+      tbest = ht;
+    }
+  }
+  t_out = tbest;
+  return best;
+}
+GRT_DEV int intersect32(const KScene& S, const Ray32& r, float& t_out) {
+  if (__builtin_expect(__any(ray_has_zero(r)), 0)) return intersect32_t<true>(S, r, t_out);
+  return intersect32_t<false>(S, r, t_out);
+}
+
+// Surface(p) for the hit object (sphere.go:56-58, aabb.go:55-72).  For a box the hit point's
+// entry-axis coordinate is snapped to the face; p is updated in place so the next ray
+// starts exactly on the face.  Returns the material index.
+GRT_DEV int surface32(const KScene& S, int id, const Ray32& r, float t, f3& p, f3& n) {
+  float4 pa = S.prims[2 * id], pb = S.prims[2 * id + 1];
+  int bits = __float_as_int(pb.w);
+  p = fma3(r.D, t, r.O);
+  if (bits & 1) {
+    // entry axis = argmax of the per-axis near distances (first axis wins ties)
+    float nx = fminf((pa.x - r.O.x) * r.invD.x, (pb.x - r.O.x) * r.invD.x);
+    float ny = fminf((pa.y - r.O.y) * r.invD.y, (pb.y - r.O.y) * r.invD.y);
+    float nz = fminf((pa.z - r.O.z) * r.invD.z, (pb.z - r.O.z) * r.invD.z);
+    int ax = (nx >= ny) ? ((nx >= nz) ? 0 : 2) : ((ny >= nz) ? 1 : 2);
+    if (ax == 0) p.x = r.D.x > 0.0f ? pa.x : pb.x;
+    if (ax == 1) p.y = r.D.y > 0.0f ? pa.y : pb.y;
+    if (ax == 2) p.z = r.D.z > 0.0f ? pa.z : pb.z;
+    const float eps = 1e-4f;
+    n = mk3(0.0f, 0.0f, 0.0f);
+    if (p.x - pa.x < eps) n.x = -1.0f;
+    else if (pb.x - p.x < eps) n.x = 1.0f;
+    else if (p.y - pa.y < eps) n.y = -1.0f;
+    else if (pb.y - p.y < eps) n.y = 1.0f;
+    else if (p.z - pa.z < eps) n.z = -1.0f;
+    else if (pb.z - p.z < eps) n.z = 1.0f;
+  } else {
+    f3 d = mk3(p.x - pa.x, p.y - pa.y, p.z - pa.z);
+    float s = rsq32(dot3(d, d));
+    n = d * (pa.w < 0.0f ? -s : s);  // Scale(Radius).Unit(): the sign of the radius survives
+  }
+  return bits >> 8;
+}
+
+// geom.SampleHemisphereNormal (vec3.go:202-218); u1,u2 in draw order.  v_sin/v_cos take
+// revolutions, so cos(2*pi*u1) is one instruction.  The result is unit to rounding; the
+// reference's final Unit() is not repeated.
+GRT_DEV f3 sample_hemi32(f3 n, float u1, float u2) {
+  float r2s = sqrt32(u2);
+  f3 u = fabsf(n.x) > 0.1f ? mk3(n.z, 0.0f, -n.x) : mk3(0.0f, -n.z, n.y);  // (0,1,0)xn | (1,0,0)xn
+  u = unit3(u);
+  f3 v = cross3(n, u);
+  float c = __builtin_amdgcn_cosf(u1) * r2s, s = __builtin_amdgcn_sinf(u1) * r2s;
+  float w = sqrt32(1.0f - u2);
+  return mk3(fmaf(u.x, c, fmaf(v.x, s, n.x * w)), fmaf(u.y, c, fmaf(v.y, s, n.y * w)),
+             fmaf(u.z, c, fmaf(v.z, s, n.z * w)));
+}
+GRT_DEV f3 reflect32(f3 v, f3 n) { return unit3(fma3(n, -2.0f * dot3(v, n), v)); }  // vec3.go:129-131
+// Vec3.Refract (vec3.go:134-159); xi replaces rand.Float64() of vec3.go:152.
+GRT_DEV bool refract32(f3 v, f3 n, float eta_ratio, float xi, f3& out) {
+  float ratio = eta_ratio;
+  f3 rn = n;
+  if (dot3(v, n) >= 0.0f) {
+    rn = -n;
+    ratio = rcp32(ratio);
+  }
+  float cosi = fminf(-dot3(v, rn), 1.0f);
+  float sini = sqrt32(1.0f - cosi * cosi);
+  bool tir = ratio * sini > 1.0f;
+  float r0 = (1.0f - ratio) * rcp32(1.0f + ratio);
+  r0 = r0 * r0;
+  float m = 1.0f - cosi, m2 = m * m;
+  r0 = fmaf(1.0f - r0, m2 * m2 * m, r0);
+  if (tir | (r0 > xi)) return false;
+  f3 r1 = fma3(rn, cosi, v) * ratio;
+  float k = -sqrt32(fabsf(1.0f - dot3(r1, r1)));
+  out = unit3(fma3(rn, k, r1));
+  return true;
+}
+
+// ---- one camera path as a resumable state --------------------------------------------
+struct PathState {
+  f3 O, D, thr;
+  uint32_t pkey;
+  int depth;
+};
+GRT_DEV void path_start(const KScene& S, int x, int y, uint32_t pix_key, uint32_t sample, PathState& st) {
+  st.pkey = grt_rng_path_key(pix_key, sample);
+  make_primary(S, x, y, grt_rng_draw(st.pkey, GRT_DIM_JITTER_U), grt_rng_draw(st.pkey, GRT_DIM_JITTER_V),
+               st.O, st.D);
+  st.thr = mk3(1.0f, 1.0f, 1.0f);
+  st.depth = 1;
+}
+
+// Direct illumination of the plain "diffuse" material (scene.go:322-346): every light is a
+// point at Pos(); the shadow loop visits every object with a shrinking tNear and marks the
+// light hidden when any non-emissive object is accepted (no distance-to-light cap).
+GRT_DEV f3 direct_light32(const KScene& S, f3 p, f3 n, f3 color) {
+  f3 result = mk3(0.0f, 0.0f, 0.0f);
+  for (int li = 0; li < S.n_lights; ++li) {
+    float4 lp = S.lights[2 * li], lc = S.lights[2 * li + 1];
+    f3 dir = unit3(mk3(lp.x - p.x, lp.y - p.y, lp.z - p.z));
+    float fd = fmaxf(dot3(n, dir), 0.0f);
+    Ray32 sr;
+    ray_setup(sr, p, dir);
+    bool careful = __any(ray_has_zero(sr));
+    float visible = 1.0f, tn = 3.402823466e38f;
+    for (int i = 0; i < S.n_prims; ++i) {
+      float4 pa = S.prims[2 * i], pb = S.prims[2 * i + 1];
+      int bits = __float_as_int(pb.w);
+      float ht;
+      if (bits & 1)
+        ht = careful ? aabb_hit32<true>(pa, pb, sr, S.bias, tn) : aabb_hit32<false>(pa, pb, sr, S.bias, tn);
+      else
+        ht = sphere_hit32(pa, pb, sr, S.bias, tn);
+      if (ht > 0.0f) {
+        if (!(bits & 2)) visible = 0.0f;
+        tn = ht;
+      }
+    }
+    float k = fd * visible;
+    result = result + mk3(color.x * k * lc.x, color.y * k * lc.y, color.z * k * lc.z);
+  }
+  return result;
+}
+
+// One level of Scene.trace (scene.go:237-349) in throughput form.  Returns true when the
+// path ended; `radiance` then holds its contribution (already multiplied by the path
+// throughput).  Otherwise st holds the next ray.  n_rays counts intersect() calls.
+GRT_DEV bool path_step(const KScene& S, PathState& st, f3& radiance, int& n_rays) {
+  Ray32 r;
+  ray_setup(r, st.O, st.D);
+  float t;
+  n_rays++;
+  int id = intersect32(S, r, t);                    // scene.go:242
+  radiance = mk3(0.0f, 0.0f, 0.0f);
+  if (id < 0) return true;                          // scene.go:244-250
+  f3 p, n;
+  int m = surface32(S, id, r, t, p, n);             // scene.go:254-255
+  float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
+  int flags = __float_as_int(m1.w);
+  f3 color = mk3(m0.x, m0.y, m0.z);
+  if (flags & GRT_MAT_NORMAL) {                     // scene.go:274-276
+    radiance = st.thr * mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);
+    return true;
+  }
+  if (m1.z > 0.0f) {                                // scene.go:278-279
+    radiance = st.thr * (color * m1.z);
+    return true;
+  }
+  const bool scatters = (flags & (GRT_MAT_LAMBERT | GRT_MAT_TRANSPARENT)) | (m1.x > 0.0f);
+  if (scatters && st.depth + 1 >= S.max_depth) return true;  // the recursive call returns black (scene.go:238)
+  if (flags & GRT_MAT_LAMBERT) {                    // scene.go:280-286
+    f3 d = sample_hemi32(n, grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 0)),
+                         grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 1)));
+    st.thr = st.thr * color;
+    st.O = p;
+    st.D = d;
+  } else if (m1.x > 0.0f) {                         // scene.go:287-294
+    f3 incident = r.D * rsq32(r.a);
+    f3 refl = reflect32(incident, n);
+    if (m1.y != 0.0f) {
+      f3 fz = sample_hemi32(n, grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 0)),
+                            grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 1)));
+      refl = fma3(fz, m1.y, refl);
+    }
+    if (!(dot3(refl, n) > 0.0f)) return true;
+    st.thr = st.thr * (color * m1.x);
+    st.O = p;
+    st.D = refl;
+  } else if (flags & GRT_MAT_TRANSPARENT) {         // scene.go:295-304
+    f3 incident = r.D * rsq32(r.a);
+    f3 dir;
+    if (!refract32(incident, n, rcp32(m0.w), grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 2)), dir))
+      dir = reflect32(incident, n);
+    st.O = p;
+    st.D = dir;
+  } else {                                          // scene.go:305-347
+    radiance = st.thr * direct_light32(S, p, n, color);
+    return true;
+  }
+  st.depth++;
+  return false;
+}
+
+// ======================================================================================
+// FP64 re-test path: the reference's arithmetic, operation for operation.
+// ======================================================================================
+struct d3 {
+  double x, y, z;
+};
+GRT_DEV d3 mkd(double x, double y, double z) {
+  d3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+struct KScene64 {
+  double cam[12];  // origin, lower_left, horizontal, vertical (camera.go:10-13)
+  double bias;
+  const double* __restrict__ prims;  // 8 doubles per prim: a[3], b[3], radius, kind
+};
+GRT_DEV double gomax64(double x, double y) {
+  if ((x == (double)INFINITY) | (y == (double)INFINITY)) return (double)INFINITY;
+  if ((x != x) | (y != y)) return (double)NAN;
+  if (x == 0.0 && x == y) return __builtin_signbit(x) ? y : x;
+  return x > y ? x : y;
+}
+GRT_DEV double gomin64(double x, double y) {
+  if ((x == -(double)INFINITY) | (y == -(double)INFINITY)) return -(double)INFINITY;
+  if ((x != x) | (y != y)) return (double)NAN;
+  if (x == 0.0 && x == y) return __builtin_signbit(x) ? x : y;
+  return x < y ? x : y;
+}
+GRT_DEV double prim_hit64(const double* P, d3 O, d3 D, double tMin, double tMax) {
+#pragma clang fp contract(off)
+  if (P[7] == 0.0) {  // sphere.go:23-46
+    double ocx = O.x - P[0], ocy = O.y - P[1], ocz = O.z - P[2];
+    double a = D.x * D.x + D.y * D.y + D.z * D.z;
+    double halfB = ocx * D.x + ocy * D.y + ocz * D.z;
+    double c = (ocx * ocx + ocy * ocy + ocz * ocz) - P[6] * P[6];
+    double disc = halfB * halfB - a * c;
+    if (disc < 0.0) return -1.0;
+    double sqrtd = __builtin_sqrt(disc);
+    double t = (-halfB - sqrtd) / a;
+    if (t > tMin && t < tMax) return t;
+    t = (-halfB + sqrtd) / a;
+    if (t > tMin && t < tMax) return t;
+    return -1.0;
+  }
+  // aabb.go:25-45
+  double nx = (P[0] - O.x) / D.x, ny = (P[1] - O.y) / D.y, nz = (P[2] - O.z) / D.z;
+  double fx = (P[3] - O.x) / D.x, fy = (P[4] - O.y) / D.y, fz = (P[5] - O.z) / D.z;
+  double n2x = gomin64(nx, fx), n2y = gomin64(ny, fy), n2z = gomin64(nz, fz);
+  double f2x = gomax64(nx, fx), f2y = gomax64(ny, fy), f2z = gomax64(nz, fz);
+  double t0 = gomax64(gomax64(n2x, n2y), n2z);
+  double t1 = gomin64(gomin64(f2x, f2y), f2z);
+  double lo = tMin, hi = tMax;
+  if (t0 > lo) lo = t0;
+  if (t1 < hi) hi = t1;
+  if (hi <= lo) return -1.0;
+  return t0;
+}
+GRT_DEV int intersect64(const KScene64& S, int n_prims, d3 O, d3 D, double& t_out) {
+  double t = 1.7976931348623157e308;
+  int hit = -1;
+  for (int i = 0; i < n_prims; ++i) {
+    double ht = prim_hit64(S.prims + 8 * i, O, D, S.bias, t);
+    if (ht > 0.0) {
+      hit = i;
+      t = ht;
+    }
+  }
+  t_out = t;
+  return hit;
+}
+GRT_DEV d3 surface64(const double* P, d3 O, d3 D, double t) {
+#pragma clang fp contract(off)
+  d3 p = mkd(O.x + D.x * t, O.y + D.y * t, O.z + D.z * t);  // ray.go:15-17
+  if (P[7] == 0.0) {                                        // sphere.go:56-58
+    double x = (p.x - P[0]) * P[6], y = (p.y - P[1]) * P[6], z = (p.z - P[2]) * P[6];
+    double k = 1.0 / __builtin_sqrt(x * x + y * y + z * z);
+    return mkd(x * k, y * k, z * k);
+  }
+  const double eps = 1e-4;  // aabb.go:55-72
+  if (p.x < P[0] + eps) return mkd(-1, 0, 0);
+  if (p.x > P[3] - eps) return mkd(1, 0, 0);
+  if (p.y < P[1] + eps) return mkd(0, -1, 0);
+  if (p.y > P[4] - eps) return mkd(0, 1, 0);
+  if (p.z < P[2] + eps) return mkd(0, 0, -1);
+  if (p.z > P[5] - eps) return mkd(0, 0, 1);
+  return mkd(0, 0, 0);
+}
+GRT_DEV void make_primary64(const KScene64& S, int W, int H, int x, int y, double ju, double jv, d3& O, d3& D) {
+#pragma clang fp contract(off)
+  double u = ((double)x + ju) / (double)W, v = ((double)y + jv) / (double)H;  // scene.go:93-94
+  const double* c = S.cam;
+  O = mkd(c[0], c[1], c[2]);
+  D = mkd(((c[3] + c[6] * u) + c[9] * v) - c[0], ((c[4] + c[7] * u) + c[10] * v) - c[1],
+          ((c[5] + c[8] * u) + c[11] * v) - c[2]);  // camera.go:37
+}
+
+// ======================================================================================
+// Decision-margin analysis for PRIMARY rays: returns true when any FP32 comparison made by
+// intersect32/surface32 could come out differently in exact arithmetic, or when the FP32
+// t / normal may be off by more than the parity tolerance.  Interval propagation with
+// first-order rounding bounds; conservative by construction, validated against the float64
+// oracle in tests/test_primary_parity.py.
+// ======================================================================================
+GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_fast) {
+  const float U = 1.2e-7f;  // 2 ulp
+  const float BIG = 3.402823466e38f;
+  // absolute error of each component of D (camera arithmetic in FP32, camera.go:37)
+  const float eD = 4.0f * U * (fabsf(S.cam.lx) + fabsf(S.cam.ly) + fabsf(S.cam.lz) + fabsf(S.cam.hx) +
+                               fabsf(S.cam.hy) + fabsf(S.cam.hz) + fabsf(S.cam.vx) + fabsf(S.cam.vy) +
+                               fabsf(S.cam.vz));
+  const float Dlen = sqrt32(r.a);
+  const f3 aO = mk3(fabsf(r.O.x), fabsf(r.O.y), fabsf(r.O.z));
+  const f3 aI = mk3(fabsf(r.invD.x), fabsf(r.invD.y), fabsf(r.invD.z));
+  // relative error of a slab distance on axis k: bound rounding + 1/D
+  const f3 rel = mk3(4.0f * U + eD * aI.x, 4.0f * U + eD * aI.y, 4.0f * U + eD * aI.z);
+  bool amb = ray_has_zero(r);
+  float tb = BIG, eb = 0.0f;  // running best t and its error bound
+  int best = -1;
+  for (int i = 0; i < S.n_prims; ++i) {
+    float4 pa = S.prims[2 * i], pb = S.prims[2 * i + 1];
+    if (__float_as_int(pb.w) & 1) {
+      float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
+      float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
+      float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
+      float ex = rel.x * fmaxf(fabsf(x0), fabsf(x1)) + U * (fmaxf(fabsf(pa.x), fabsf(pb.x)) + 2.0f * aO.x) * aI.x;
+      float ey = rel.y * fmaxf(fabsf(y0), fabsf(y1)) + U * (fmaxf(fabsf(pa.y), fabsf(pb.y)) + 2.0f * aO.y) * aI.y;
+      float ez = rel.z * fmaxf(fabsf(z0), fabsf(z1)) + U * (fmaxf(fabsf(pa.z), fabsf(pb.z)) + 2.0f * aO.z) * aI.z;
+      float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
+      float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
+      float t0 = fmaxf(fmaxf(nx, ny), nz);
+      float t0lo = fmaxf(fmaxf(nx - ex, ny - ey), nz - ez), t0hi = fmaxf(fmaxf(nx + ex, ny + ey), nz + ez);
+      float t1lo = fminf(fminf(fx - ex, fy - ey), fz - ez), t1hi = fminf(fminf(fx + ex, fy + ey), fz + ez);
+      float lo_lo = fmaxf(S.bias, t0lo), lo_hi = fmaxf(S.bias, t0hi);
+      float hi_lo = fminf(tb - eb, t1lo), hi_hi = fminf(tb + eb, t1hi);
+      bool def_hit = hi_lo > lo_hi, def_miss = hi_hi < lo_lo;
+      if (!def_hit && !def_miss) amb = true;
+      if (def_hit) {
+        if (t0lo > 0.0f) {
+          best = i;
+          tb = t0;
+          eb = fmaxf(t0hi - t0, t0 - t0lo);
+        } else if (!(t0hi < 0.0f)) {
+          amb = true;
+        }
+      }
+    } else {
+      f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
+      float aoc = fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z);
+      float eoc = U * (aO.x + aO.y + aO.z + fabsf(pa.x) + fabsf(pa.y) + fabsf(pa.z));
+      float halfB = dot3(oc, r.D);
+      float k = halfB * r.inva;
+      f3 l = fma3(r.D, -k, oc);
+      float ll = dot3(l, l);
+      float dp = pb.x - ll;
+      float e_hb = aoc * 1.8f * eD + 1.8f * Dlen * eoc + 3.0f * U * aoc * Dlen;
+      float rel_a = 3.6f * eD * rcp32(Dlen) + 3.0f * U;
+      float ek = e_hb * r.inva + fabsf(k) * (rel_a + 2.0f * U);
+      float el = 1.8f * eoc + ek * Dlen + fabsf(k) * 1.8f * eD + 2.0f * U * (aoc + fabsf(k) * Dlen);
+      float edp = 2.0f * sqrt32(ll) * el + el * el + 2.0f * U * (pb.x + ll);
+      if (dp + edp < 0.0f) continue;  // definitely no real root
+      if (dp - edp <= 0.0f) {
+        amb = true;
+        continue;
+      }
+      float s2 = dp * r.inva, es2 = (edp + dp * rel_a) * r.inva + U * s2;
+      float sq = sqrt32(s2);
+      float es = es2 * rcp32(sq + sqrt32(fmaxf(s2 - es2, 0.0f))) + U * sq;
+      float et = ek + es + U * (fabsf(k) + sq);
+      float t1 = -k - sq, t2 = -k + sq;
+      float hi_lo = tb - eb, hi_hi = tb + eb;
+      float t = -1.0f;
+      bool in1 = (t1 - et > S.bias) && (t1 + et < hi_lo), out1 = (t1 + et <= S.bias) || (t1 - et >= hi_hi);
+      if (in1) {
+        t = t1;
+      } else if (!out1) {
+        amb = true;
+      } else {
+        bool in2 = (t2 - et > S.bias) && (t2 + et < hi_lo), out2 = (t2 + et <= S.bias) || (t2 - et >= hi_hi);
+        if (in2) t = t2;
+        else if (!out2) amb = true;
+      }
+      if (t > 0.0f) {
+        best = i;
+        tb = t;
+        eb = et;
+      }
+    }
+  }
+  if (best != id_fast) amb = true;  // cannot happen for unambiguous lanes; belt and braces
+  if (best < 0 || amb) return amb;
+  if (!(fabsf(tb - t_fast) <= eb)) return true;
+  if (eb > 3e-6f * fabsf(tb)) return true;  // t must hold 1e-5 relative
+  float4 pa = S.prims[2 * best], pb = S.prims[2 * best + 1];
+  // position error of p = O + t D
+  float ep = fabsf(tb) * eD + eb * Dlen + 2.0f * U * (aO.x + aO.y + aO.z + fabsf(tb) * Dlen);
+  if (__float_as_int(pb.w) & 1) {
+    float x0 = (pa.x - r.O.x) * r.invD.x, x1 = (pb.x - r.O.x) * r.invD.x;
+    float y0 = (pa.y - r.O.y) * r.invD.y, y1 = (pb.y - r.O.y) * r.invD.y;
+    float z0 = (pa.z - r.O.z) * r.invD.z, z1 = (pb.z - r.O.z) * r.invD.z;
+    float ex = rel.x * fmaxf(fabsf(x0), fabsf(x1)) + U * (fmaxf(fabsf(pa.x), fabsf(pb.x)) + 2.0f * aO.x) * aI.x;
+    float ey = rel.y * fmaxf(fabsf(y0), fabsf(y1)) + U * (fmaxf(fabsf(pa.y), fabsf(pb.y)) + 2.0f * aO.y) * aI.y;
+    float ez = rel.z * fmaxf(fabsf(z0), fabsf(z1)) + U * (fmaxf(fabsf(pa.z), fabsf(pb.z)) + 2.0f * aO.z) * aI.z;
+    float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
+    int ax = (nx >= ny) ? ((nx >= nz) ? 0 : 2) : ((ny >= nz) ? 1 : 2);
+    float na = ax == 0 ? nx : (ax == 1 ? ny : nz), ea = ax == 0 ? ex : (ax == 1 ? ey : ez);
+    if (ax != 0 && nx + ex >= na - ea) return true;
+    if (ax != 1 && ny + ey >= na - ea) return true;
+    if (ax != 2 && nz + ez >= na - ea) return true;
+    const float eps = 1e-4f;
+    f3 p = fma3(r.D, tb, r.O);
+    // axes tested before the entry axis by the cascade (aabb.go:57-70) must miss clearly
+    float m = ep + eps * 0.01f;
+    if (ax > 0 && (fabsf(p.x - pa.x - eps) <= m + U * fabsf(pa.x) || fabsf(pb.x - p.x - eps) <= m + U * fabsf(pb.x)))
+      return true;
+    if (ax > 1 && (fabsf(p.y - pa.y - eps) <= m + U * fabsf(pa.y) || fabsf(pb.y - p.y - eps) <= m + U * fabsf(pb.y)))
+      return true;
+    float w = ax == 0 ? pb.x - pa.x : (ax == 1 ? pb.y - pa.y : pb.z - pa.z);
+    if (fabsf(w - eps) <= 1e-5f) return true;  // degenerate slab as thin as the epsilon
+  } else {
+    // sphere normal error ~ position error / radius
+    if (ep > 6e-6f * fabsf(pa.w)) return true;
+  }
+  return false;
+}

@@ -1,0 +1,24 @@
+// grt_internal.h — shared between the translation units of libgrt_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+
+#include "../../include/grt.h"
+
+// The linear-scan kernels (the reference's own algorithm, scene.go:173) read every object
+// for every ray; beyond this many objects a scene goes through the BVH path instead.
+#define GRT_MAX_LINEAR_PRIMS 4096
+
+int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define GRT_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return grt_fail(GRT_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct KScene;
+// Stages `s` on the current device if needed and fills the kernel-side view.
+int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks);
+const grt_scene_desc* grt_scene_desc_of(const grt_scene* s);

@@ -1,0 +1,225 @@
+// grt_kernels.h — the render kernels (gfx950).  Included once, by grt_api.hip.
+//
+// k_pathtrace     Scene.Render's per-pixel sample loop (scene.go:86-104) with trace()
+//                 (scene.go:237-349) unrolled into a per-lane state machine
+// k_sum_chunks    fixed-order reduction of the per-chunk partial sums
+// k_tonemap       mean -> Gamma(2) -> Clamp -> uint8(255.99 c), B,G,R  (scene.go:98-99,67-74)
+// k_trace_samples per-sample radiance of chosen pixels (parity aid)
+// k_primary_hits  Camera.Ray + intersect + Surface per pixel, FP32 with FP64 re-test (C2)
+// k_primary_sweep FP32 intersection roofline loop (C2 roofline variant)
+#pragma once
+#include "grt_device.h"
+
+// Work decomposition of one shard of a frame.  A wave owns one 8x8 pixel tile for one chunk
+// of the sample range; tile rows coincide with the GRT_BAND_ROWS-row bands that are dealt
+// round-robin to shards, so a shard's tiles are whole.
+struct RenderJob {
+  int shard, n_shards;  // this shard renders bands shard, shard+n_shards, ...
+  int rows_local;       // rows this shard owns (packed, ascending)
+  int tiles_x, n_tiles; // 8x8 tiles across, and in total for this shard
+  int n_chunks, chunk_spp, spp;
+};
+
+GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
+  unsigned long long s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
+
+// One wave = one (tile, chunk) work item; one lane = one pixel.  Each lane runs its pixel's
+// samples back to back: when its path ends it adds the radiance and starts the next sample
+// in the same loop iteration, so every iteration of the wave-wide loop does one intersect()
+// for every lane that still has samples left — terminated paths never leave idle lanes
+// behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
+__global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
+                                                   unsigned long long* __restrict__ ray_count) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
+  const int tile = item % J.n_tiles, chunk = item / J.n_tiles;
+  const int tx = tile % J.tiles_x, lband = tile / J.tiles_x;
+  const int x = tx * 8 + (lane & 7);
+  const int y = (J.shard + lband * J.n_shards) * 8 + (lane >> 3);
+  const int lrow = lband * 8 + (lane >> 3);
+  const bool valid = (x < S.W) & (y < S.H);
+
+  int s = chunk * J.chunk_spp;
+  const int s_end = min(s + J.chunk_spp, J.spp);
+  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+
+  f3 acc = mk3(0.0f, 0.0f, 0.0f);
+  int n_rays = 0;
+  bool alive = valid & (s < s_end);
+  PathState st;
+  st.O = st.D = st.thr = mk3(0.0f, 0.0f, 1.0f);
+  st.pkey = 0;
+  st.depth = 1;
+  if (alive) path_start(S, x, y, pix_key, (uint32_t)s, st);
+  while (__any(alive)) {
+    if (alive) {
+      f3 rad;
+      if (path_step(S, st, rad, n_rays)) {
+        acc = acc + rad;  // scene.go:96
+        ++s;
+        if (s < s_end)
+          path_start(S, x, y, pix_key, (uint32_t)s, st);
+        else
+          alive = false;
+      }
+    }
+  }
+  if (valid) {
+    float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
+    o[0] = acc.x;
+    o[1] = acc.y;
+    o[2] = acc.z;
+  }
+  if (ray_count) {
+    unsigned long long tot = wave_sum_u32((unsigned)n_rays);
+    if (lane == 0) atomicAdd(ray_count, tot);
+  }
+}
+
+// out[i] = slab[0][i] + slab[1][i] + ... in chunk order (bitwise reproducible).
+__global__ __launch_bounds__(256) void k_sum_chunks(const float* __restrict__ slab, int n_chunks, size_t n,
+                                                    float* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float a = slab[i];
+    for (int c = 1; c < n_chunks; ++c) a += slab[(size_t)c * n + i];
+    out[i] = a;
+  }
+}
+
+// scene.go:98-99 + WriteColor (scene.go:67-74): c = sum/samples; Gamma(2) = sqrt; Clamp =
+// min(1, c); uint8(255.99*c) truncation; bytes B,G,R.  bpp >= 3; byte 3.. untouched.
+__global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb_sum, int W, int rows,
+                                                 float inv_samples, uint8_t* __restrict__ bgr, int pitch,
+                                                 int bpp) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)W * (size_t)rows, stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const size_t yy = i / (size_t)W, xx = i - yy * (size_t)W;
+    const float* c = rgb_sum + i * 3;
+    // correctly rounded sqrt: the byte must not depend on a 1-ulp sqrt difference
+    float r = fminf(1.0f, __fsqrt_rn(c[0] * inv_samples));
+    float g = fminf(1.0f, __fsqrt_rn(c[1] * inv_samples));
+    float b = fminf(1.0f, __fsqrt_rn(c[2] * inv_samples));
+    uint8_t* o = bgr + yy * (size_t)pitch + xx * (size_t)bpp;
+    o[0] = (uint8_t)(255.99f * b);
+    o[1] = (uint8_t)(255.99f * g);
+    o[2] = (uint8_t)(255.99f * r);
+  }
+}
+
+// One thread per (pixel, sample): rgb = trace(), n_rays = intersect() calls.
+__global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __restrict__ pixel_xy, int n_pixels,
+                                                       int samples, float* __restrict__ rgb,
+                                                       int* __restrict__ n_rays_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < (size_t)n_pixels * (size_t)samples;
+  const size_t j = valid ? i : 0;
+  const int pi = (int)(j / (size_t)samples), s = (int)(j % (size_t)samples);
+  const int x = pixel_xy[2 * pi], y = pixel_xy[2 * pi + 1];
+  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  PathState st;
+  path_start(S, x, y, pix_key, (uint32_t)s, st);
+  f3 rad = mk3(0.0f, 0.0f, 0.0f);
+  int n_rays = 0;
+  bool alive = valid;
+  while (__any(alive)) {
+    if (alive) {
+      f3 r;
+      if (path_step(S, st, r, n_rays)) {
+        rad = r;
+        alive = false;
+      }
+    }
+  }
+  if (valid) {
+    rgb[i * 3 + 0] = rad.x;
+    rgb[i * 3 + 1] = rad.y;
+    rgb[i * 3 + 2] = rad.z;
+    if (n_rays_out) n_rays_out[i] = n_rays;
+  }
+}
+
+// Config C2, parity variant.  FP32 intersect32/surface32 (the functions the renderer uses);
+// lanes whose decision margin is small (ambiguous32) are re-tested in FP64 with the
+// reference's operation order, which makes hit/miss and the object id bit-exact.
+__global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, int jitter_mode, int* __restrict__ id_out,
+                                                      float* __restrict__ t_out, float* __restrict__ n_out,
+                                                      unsigned long long* __restrict__ fallback_count,
+                                                      int force_mode /*0 auto, 1 all FP32, 2 all FP64*/) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)S.W * (size_t)S.H;
+  const bool valid = i < n;
+  const size_t j = valid ? i : 0;
+  const int y = (int)(j / (size_t)S.W), x = (int)(j - (size_t)y * (size_t)S.W);
+  uint32_t b0 = 1u << 23, b1 = 1u << 23;  // 0.5 * 2^24
+  if (jitter_mode == 1) {
+    uint32_t pk = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)j), 0);
+    b0 = grt_rng_bits24(pk, GRT_DIM_JITTER_U);
+    b1 = grt_rng_bits24(pk, GRT_DIM_JITTER_V);
+  }
+  f3 O, D;
+  make_primary(S, x, y, (float)b0 * (1.0f / 16777216.0f), (float)b1 * (1.0f / 16777216.0f), O, D);
+  Ray32 r;
+  ray_setup(r, O, D);
+  float t;
+  int id = intersect32(S, r, t);
+  f3 p, nn = mk3(0.0f, 0.0f, 0.0f);
+  if (id >= 0) surface32(S, id, r, t, p, nn);
+  else t = 0.0f;
+  bool amb = force_mode == 2 || (force_mode == 0 && ambiguous32(S, r, id, t));
+  if (amb) {
+    d3 O64, D64;
+    make_primary64(S64, S.W, S.H, x, y, (double)b0 * (1.0 / 16777216.0), (double)b1 * (1.0 / 16777216.0), O64, D64);
+    double t64;
+    id = intersect64(S64, S.n_prims, O64, D64, t64);
+    nn = mk3(0.0f, 0.0f, 0.0f);
+    t = 0.0f;
+    if (id >= 0) {
+      d3 n64 = surface64(S64.prims + 8 * id, O64, D64, t64);
+      nn = mk3((float)n64.x, (float)n64.y, (float)n64.z);
+      t = (float)t64;
+    }
+  }
+  if (valid) {
+    id_out[i] = id;
+    t_out[i] = t;
+    n_out[i * 3 + 0] = nn.x;
+    n_out[i * 3 + 1] = nn.y;
+    n_out[i * 3 + 2] = nn.z;
+  }
+  if (fallback_count) {
+    unsigned long long m = __ballot(amb && valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(fallback_count, (unsigned long long)__popcll(m));
+  }
+}
+
+// Config C2, roofline variant: `samples` jittered primary rays per pixel
+// in-kernel, FP32 only, one checksum word per pixel = sum of (id+1).  A wave owns an 8x8
+// tile so its rays are coherent.
+__global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum) {
+  const int lane = threadIdx.x & 63;
+  const int tiles_x = (S.W + 7) >> 3, tiles_y = (S.H + 7) >> 3;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= tiles_x * tiles_y) return;
+  const int x = (tile % tiles_x) * 8 + (lane & 7), y = (tile / tiles_x) * 8 + (lane >> 3);
+  const bool valid = (x < S.W) & (y < S.H);
+  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  uint32_t sum = 0;
+  for (int s = 0; s < samples; ++s) {
+    uint32_t pk = grt_rng_path_key(pix_key, (uint32_t)s);
+    f3 O, D;
+    make_primary(S, x, y, grt_rng_draw(pk, GRT_DIM_JITTER_U), grt_rng_draw(pk, GRT_DIM_JITTER_V), O, D);
+    Ray32 r;
+    ray_setup(r, O, D);
+    float t;
+    sum += (uint32_t)(intersect32(S, r, t) + 1);
+  }
+  if (valid) checksum[(size_t)y * (size_t)S.W + (size_t)x] = sum;
+}

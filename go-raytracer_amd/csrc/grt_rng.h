@@ -1,0 +1,59 @@
+// grt_rng.h — counter-based RNG shared by host and device code.
+//
+// Replaces the reference's sequential math/rand streams (pkg/tracer/scene.go:86,93-94,114
+// and the process-global source at pkg/geom/vec3.go:152).  A uniform is named by
+// (seed, pixel, sample, dimension); there is no state to carry between draws, so a lane can
+// start any sample of any pixel and the image does not depend on how the work is sharded.
+//
+//   mix32       2-multiply avalanche hash ("lowbias32"), a bijection on 32 bits
+//   pixel_key   once per pixel  (per lane, amortised over all samples of the pixel)
+//   path_key    once per path
+//   draw        one mix32 per uniform; 24 random bits -> exactly representable in f32 and f64
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GRT_HD __host__ __device__ __forceinline__
+#else
+#define GRT_HD static inline
+#endif
+
+GRT_HD uint32_t grt_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+GRT_HD uint32_t grt_rng_seed32(uint64_t seed) {
+  return grt_mix32((uint32_t)seed ^ 0x9e3779b9U) ^ grt_mix32((uint32_t)(seed >> 32) + 0x85ebca6bU);
+}
+GRT_HD uint32_t grt_rng_pixel_key(uint32_t seed32, uint32_t pixel) {
+  return grt_mix32(seed32 ^ (pixel * 0x9E3779B1U));
+}
+GRT_HD uint32_t grt_rng_path_key(uint32_t pixel_key, uint32_t sample) {
+  return grt_mix32(pixel_key + sample * 0x85EBCA77U + 0xC2B2AE3DU);
+}
+GRT_HD uint32_t grt_rng_bits24(uint32_t path_key, uint32_t dim) {
+  return grt_mix32(path_key + (dim + 1U) * 0x9E3779B9U) >> 8;
+}
+GRT_HD float grt_rng_draw(uint32_t path_key, uint32_t dim) {
+  return (float)grt_rng_bits24(path_key, dim) * (1.0f / 16777216.0f);
+}
+GRT_HD double grt_rng_draw64(uint32_t path_key, uint32_t dim) {
+  return (double)grt_rng_bits24(path_key, dim) * (1.0 / 16777216.0);
+}
+
+// Dimension layout of one camera path: 0,1 = pixel jitter (scene.go:93-94); the hit at depth
+// d (1-based, scene.go:237) owns 2+3(d-1)+{0,1} for SampleHemisphereNormal's two draws in
+// call order (vec3.go:203-204) and +2 for Refract's roulette (vec3.go:152).
+#define GRT_DIM_JITTER_U 0u
+#define GRT_DIM_JITTER_V 1u
+#define GRT_DIM_HIT(depth, k) (2u + 3u * (uint32_t)((depth)-1) + (uint32_t)(k))
+
+// Photon walks (scene.go:140-165, 354-424) use pixel = photon index, sample = map id:
+// 0,1 = emission direction; bounce d owns 2+4(d-1)+{0,1} hemisphere, +2 Refract, +3 roulette.
+#define GRT_PDIM_EMIT_U 0u
+#define GRT_PDIM_EMIT_V 1u
+#define GRT_PDIM_HIT(depth, k) (2u + 4u * (uint32_t)((depth)-1) + (uint32_t)(k))
