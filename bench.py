@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its own config.
+
+Workload (config C3): the README "final scene" (cornell8, cmd/raytracer/
+main.go:32-59) at 1920x1080, aspect 16/9, 1000 samples per pixel, depth cap 6, seed 1,
+tile-sharded over the ranks in interleaved 8-row bands.  One step = one whole frame: every
+rank path-traces its bands (grt_render_accum_dev) and rank 0 gathers them over RCCL.
+Total work is fixed as N grows ("strong" scaling).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = paths (camera samples) per second over the whole
+job in Msamples/s, inputs (the scene) resident in HBM before the timed region.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_RAY_INTERSECT = 204  # 6 x AABB.Hit (25) + 2 x Sphere.Hit (27), SURVEY.md §8d
+FLOP_PER_RAY_SHADED = 324     # + ~120 shading flop per ray (Unit, At, Surface, BSDF sample)
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(pkg, width, height):
+    """The float64 C restatement of the reference (oracle/, kind "port") on the host cores,
+    same scene and resolution at a bounded sample count."""
+    from oracle import binding as ob
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    spp = 8
+    s = ob.OracleScene(pkg.scenes.cornell_flat(width, height))
+    s.RenderAccum(1, seed=1, row_begin=0, row_end=min(64, height), nthreads=threads)  # warm up threads / caches
+    t0 = time.perf_counter()
+    s.RenderAccum(spp, seed=1, nthreads=threads)
+    dt = time.perf_counter() - t0
+    n = width * height * spp
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"cornell8 {width}x{height} at {spp} spp (all rows), float64 C restatement of the Go "
+                      f"reference, {threads} worker threads, {dt:.2f} s wall",
+            "rays_per_s": s.last_ray_count() / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--chunk-spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("go-raytracer_amd")
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    W, H, S = args.width, args.height, args.spp
+    scene = pkg.scenes.cornell(W, H)
+    ren = shard.ShardRenderer(scene, S, rank, world, seed=1, chunk_spp=args.chunk_spp, device=dev)
+
+    def step():
+        ren.render()
+        return ren.gather(0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ren.ray_count.zero_()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    frame = None
+    for k in range(args.steps):
+        ev[k][0].record()   # same stream the kernels are enqueued on (torch's current stream)
+        ren.render()
+        ev[k][1].record()
+        frame = ren.gather(0)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    stats = torch.tensor([elapsed, kernel_ms, float(ren.ray_count.item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms, rays = mx[0].item(), mx[1].item(), sm[2].item()
+    else:
+        rays = stats[2].item()
+
+    if rank == 0:
+        samples_total = float(W) * H * S * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        rays_per_launch_rank = rays / args.steps / world       # average over ranks
+        rays_per_s = rays / elapsed
+        # roofline of the dominant kernel (k_pathtrace), per launch on one GPU
+        achieved = rays_per_launch_rank * FLOP_PER_RAY_SHADED / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and (W, H, S, world) == (1920, 1080, 1000, 1):
+            traffic = json.load(open(tpath)).get("k_pathtrace_hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/s (paths/s) at 1920x1080",
+            "value": samples_total / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C3: cornell8 (README final scene, main.go:32-59) {W}x{H} aspect {W}/{H}, "
+                                   f"{S} spp, depth cap 6, seed 1, path tracing",
+                       "parallelism": f"tile-sharded, interleaved 8-row bands over {world} GPU(s), "
+                                      "RCCL gather of finished bands to rank 0",
+                       "chunk_spp": args.chunk_spp or "auto"},
+            "rays_per_s": rays_per_s,
+            "rays_per_sample": rays / samples_total,
+            "roofline": {
+                "bound": "valu_fp32",
+                "kernel": "k_pathtrace",
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": traffic,
+                "flop_per_ray": FLOP_PER_RAY_SHADED,
+                "achieved_intersection_only": rays_per_launch_rank * FLOP_PER_RAY_INTERSECT / (kernel_ms * 1e-3) / 1e12,
+                "kernel_ms_per_launch": kernel_ms,
+                "rays_per_launch": rays_per_launch_rank,
+                "note": "algorithmic flop per intersect() call x calls per launch / HIP-event time of the launch; "
+                        "div and sqrt count 1 flop (SURVEY.md §8d); MFMA is not used: nothing here is a contraction",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, W, H)
+        assert frame is not None and tuple(frame.shape) == (H, W, 3)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

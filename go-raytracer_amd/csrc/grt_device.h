@@ -101,6 +101,7 @@ GRT_DEV void ray_setup(Ray32& r, f3 O, f3 D) {
 GRT_DEV bool ray_has_zero(const Ray32& r) { return (r.D.x == 0.0f) | (r.D.y == 0.0f) | (r.D.z == 0.0f); }
 
 // Camera.Ray (camera.go:34-39): D = lowerLeft + horizontal*u + vertical*v - origin, unnormalised.
+// FP32 version used by the renderer (the pixel jitter is random anyway).
 GRT_DEV void make_primary(const KScene& S, int x, int y, float ju, float jv, f3& O, f3& D) {
   float u = ((float)x + ju) * (1.0f / (float)S.W);
   float v = ((float)y + jv) * (1.0f / (float)S.H);
@@ -456,22 +457,24 @@ GRT_DEV void make_primary64(const KScene64& S, int W, int H, int x, int y, doubl
 // ======================================================================================
 // Decision-margin analysis for PRIMARY rays: returns true when any FP32 comparison made by
 // intersect32/surface32 could come out differently in exact arithmetic, or when the FP32
-// t / normal may be off by more than the parity tolerance.  Interval propagation with
-// first-order rounding bounds; conservative by construction, validated against the float64
-// oracle in tests/test_primary_parity.py.
+// t / normal may miss the parity tolerance (1e-5 relative).  First-order interval
+// propagation; u = 2^-24 is the FP32 unit roundoff.  Preconditions: r.D is the float64
+// direction rounded once to FP32 (k_primary_hits), r.O is exact or rounded once.
+// Conservative by construction and validated against the float64 oracle in
+// tests/test_gpu_primary.py.
 // ======================================================================================
+GRT_DEV float slab_err(float lo, float hi, float o, float inv, float k0, float k1) {
+  const float u = 6.0e-8f;
+  // t = b*inv - o*inv: each product carries the roundings of b, 1/D (rcp, 1 ulp), D and the
+  // product itself; the fma adds one more on the result
+  return 3.0f * u * (fmaxf(fabsf(lo), fabsf(hi)) + fabsf(o)) * fabsf(inv) + 2.0f * u * fmaxf(fabsf(k0), fabsf(k1));
+}
+
 GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_fast) {
-  const float U = 1.2e-7f;  // 2 ulp
+  const float u = 6.0e-8f;
   const float BIG = 3.402823466e38f;
-  // absolute error of each component of D (camera arithmetic in FP32, camera.go:37)
-  const float eD = 4.0f * U * (fabsf(S.cam.lx) + fabsf(S.cam.ly) + fabsf(S.cam.lz) + fabsf(S.cam.hx) +
-                               fabsf(S.cam.hy) + fabsf(S.cam.hz) + fabsf(S.cam.vx) + fabsf(S.cam.vy) +
-                               fabsf(S.cam.vz));
   const float Dlen = sqrt32(r.a);
-  const f3 aO = mk3(fabsf(r.O.x), fabsf(r.O.y), fabsf(r.O.z));
-  const f3 aI = mk3(fabsf(r.invD.x), fabsf(r.invD.y), fabsf(r.invD.z));
-  // relative error of a slab distance on axis k: bound rounding + 1/D
-  const f3 rel = mk3(4.0f * U + eD * aI.x, 4.0f * U + eD * aI.y, 4.0f * U + eD * aI.z);
+  const float Olen = sqrt32(dot3(r.O, r.O));
   bool amb = ray_has_zero(r);
   float tb = BIG, eb = 0.0f;  // running best t and its error bound
   int best = -1;
@@ -481,9 +484,9 @@ GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_f
       float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
       float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
       float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
-      float ex = rel.x * fmaxf(fabsf(x0), fabsf(x1)) + U * (fmaxf(fabsf(pa.x), fabsf(pb.x)) + 2.0f * aO.x) * aI.x;
-      float ey = rel.y * fmaxf(fabsf(y0), fabsf(y1)) + U * (fmaxf(fabsf(pa.y), fabsf(pb.y)) + 2.0f * aO.y) * aI.y;
-      float ez = rel.z * fmaxf(fabsf(z0), fabsf(z1)) + U * (fmaxf(fabsf(pa.z), fabsf(pb.z)) + 2.0f * aO.z) * aI.z;
+      float ex = slab_err(pa.x, pb.x, r.O.x, r.invD.x, x0, x1);
+      float ey = slab_err(pa.y, pb.y, r.O.y, r.invD.y, y0, y1);
+      float ez = slab_err(pa.z, pb.z, r.O.z, r.invD.z, z0, z1);
       float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
       float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
       float t0 = fmaxf(fmaxf(nx, ny), nz);
@@ -503,28 +506,28 @@ GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_f
         }
       }
     } else {
-      f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
-      float aoc = fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z);
-      float eoc = U * (aO.x + aO.y + aO.z + fabsf(pa.x) + fabsf(pa.y) + fabsf(pa.z));
+      f3 C = mk3(pa.x, pa.y, pa.z);
+      f3 oc = r.O - C;
+      float ocl = sqrt32(dot3(oc, oc));
+      float eoc = 1.5f * u * (sqrt32(dot3(C, C)) + Olen + ocl);  // |delta oc|
       float halfB = dot3(oc, r.D);
       float k = halfB * r.inva;
       f3 l = fma3(r.D, -k, oc);
-      float ll = dot3(l, l);
+      float ll = dot3(l, l), ln = sqrt32(ll);
       float dp = pb.x - ll;
-      float e_hb = aoc * 1.8f * eD + 1.8f * Dlen * eoc + 3.0f * U * aoc * Dlen;
-      float rel_a = 3.6f * eD * rcp32(Dlen) + 3.0f * U;
-      float ek = e_hb * r.inva + fabsf(k) * (rel_a + 2.0f * U);
-      float el = 1.8f * eoc + ek * Dlen + fabsf(k) * 1.8f * eD + 2.0f * U * (aoc + fabsf(k) * Dlen);
-      float edp = 2.0f * sqrt32(ll) * el + el * el + 2.0f * U * (pb.x + ll);
+      float e_hb = Dlen * eoc + 4.0f * u * ocl * Dlen;
+      float ek = e_hb * r.inva + 8.0f * u * fabsf(k);
+      float el = eoc + ek * Dlen + 2.0f * u * (fabsf(k) * Dlen + ln);
+      float edp = 2.0f * ln * el + el * el + 3.0f * u * (ll + pb.x);
       if (dp + edp < 0.0f) continue;  // definitely no real root
       if (dp - edp <= 0.0f) {
         amb = true;
         continue;
       }
-      float s2 = dp * r.inva, es2 = (edp + dp * rel_a) * r.inva + U * s2;
+      float s2 = dp * r.inva, es2 = edp * r.inva + 8.0f * u * s2;
       float sq = sqrt32(s2);
-      float es = es2 * rcp32(sq + sqrt32(fmaxf(s2 - es2, 0.0f))) + U * sq;
-      float et = ek + es + U * (fabsf(k) + sq);
+      float es = es2 * rcp32(sq + sqrt32(fmaxf(s2 - es2, 0.0f))) + 2.0f * u * sq;
+      float et = ek + es + 2.0f * u * (fabsf(k) + sq);
       float t1 = -k - sq, t2 = -k + sq;
       float hi_lo = tb - eb, hi_hi = tb + eb;
       float t = -1.0f;
@@ -548,17 +551,16 @@ GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_f
   if (best != id_fast) amb = true;  // cannot happen for unambiguous lanes; belt and braces
   if (best < 0 || amb) return amb;
   if (!(fabsf(tb - t_fast) <= eb)) return true;
-  if (eb > 3e-6f * fabsf(tb)) return true;  // t must hold 1e-5 relative
+  if (eb > 8e-6f * fabsf(tb)) return true;  // t must hold 1e-5 relative
   float4 pa = S.prims[2 * best], pb = S.prims[2 * best + 1];
-  // position error of p = O + t D
-  float ep = fabsf(tb) * eD + eb * Dlen + 2.0f * U * (aO.x + aO.y + aO.z + fabsf(tb) * Dlen);
+  f3 p = fma3(r.D, tb, r.O);
   if (__float_as_int(pb.w) & 1) {
     float x0 = (pa.x - r.O.x) * r.invD.x, x1 = (pb.x - r.O.x) * r.invD.x;
     float y0 = (pa.y - r.O.y) * r.invD.y, y1 = (pb.y - r.O.y) * r.invD.y;
     float z0 = (pa.z - r.O.z) * r.invD.z, z1 = (pb.z - r.O.z) * r.invD.z;
-    float ex = rel.x * fmaxf(fabsf(x0), fabsf(x1)) + U * (fmaxf(fabsf(pa.x), fabsf(pb.x)) + 2.0f * aO.x) * aI.x;
-    float ey = rel.y * fmaxf(fabsf(y0), fabsf(y1)) + U * (fmaxf(fabsf(pa.y), fabsf(pb.y)) + 2.0f * aO.y) * aI.y;
-    float ez = rel.z * fmaxf(fabsf(z0), fabsf(z1)) + U * (fmaxf(fabsf(pa.z), fabsf(pb.z)) + 2.0f * aO.z) * aI.z;
+    float ex = slab_err(pa.x, pb.x, r.O.x, r.invD.x, x0, x1);
+    float ey = slab_err(pa.y, pb.y, r.O.y, r.invD.y, y0, y1);
+    float ez = slab_err(pa.z, pb.z, r.O.z, r.invD.z, z0, z1);
     float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
     int ax = (nx >= ny) ? ((nx >= nz) ? 0 : 2) : ((ny >= nz) ? 1 : 2);
     float na = ax == 0 ? nx : (ax == 1 ? ny : nz), ea = ax == 0 ? ex : (ax == 1 ? ey : ez);
@@ -566,18 +568,25 @@ GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_f
     if (ax != 1 && ny + ey >= na - ea) return true;
     if (ax != 2 && nz + ez >= na - ea) return true;
     const float eps = 1e-4f;
-    f3 p = fma3(r.D, tb, r.O);
-    // axes tested before the entry axis by the cascade (aabb.go:57-70) must miss clearly
-    float m = ep + eps * 0.01f;
-    if (ax > 0 && (fabsf(p.x - pa.x - eps) <= m + U * fabsf(pa.x) || fabsf(pb.x - p.x - eps) <= m + U * fabsf(pb.x)))
-      return true;
-    if (ax > 1 && (fabsf(p.y - pa.y - eps) <= m + U * fabsf(pa.y) || fabsf(pb.y - p.y - eps) <= m + U * fabsf(pb.y)))
-      return true;
+    // axes the cascade (aabb.go:57-70) tests before the entry axis must miss clearly:
+    // error of p.k = O.k + t D.k, plus the rounding of the bound
+    float mx = 2.0f * (fabsf(tb * r.D.x) * 2.0f * u + eb * fabsf(r.D.x) + u * (fabsf(p.x) + fabsf(pa.x) + fabsf(pb.x))) + 1e-7f;
+    float my = 2.0f * (fabsf(tb * r.D.y) * 2.0f * u + eb * fabsf(r.D.y) + u * (fabsf(p.y) + fabsf(pa.y) + fabsf(pb.y))) + 1e-7f;
+    if (ax > 0 && (fabsf(p.x - pa.x - eps) <= mx || fabsf(pb.x - p.x - eps) <= mx)) return true;
+    if (ax > 1 && (fabsf(p.y - pa.y - eps) <= my || fabsf(pb.y - p.y - eps) <= my)) return true;
     float w = ax == 0 ? pb.x - pa.x : (ax == 1 ? pb.y - pa.y : pb.z - pa.z);
     if (fabsf(w - eps) <= 1e-5f) return true;  // degenerate slab as thin as the epsilon
   } else {
-    // sphere normal error ~ position error / radius
-    if (ep > 6e-6f * fabsf(pa.w)) return true;
+    // n = (p - C)/|p - C|: lateral error of p over R, plus the error along the ray scaled by
+    // the sine of the angle between ray and normal (= |l| / R)
+    f3 C = mk3(pa.x, pa.y, pa.z);
+    f3 oc = r.O - C;
+    float k = dot3(oc, r.D) * r.inva;
+    f3 l = fma3(r.D, -k, oc);
+    float R = fabsf(pa.w), sinphi = fminf(1.0f, sqrt32(dot3(l, l)) * rcp32(R));
+    float lateral = fabsf(tb) * 2.0f * u * Dlen + 2.0f * u * (sqrt32(dot3(p, p)) + sqrt32(dot3(C, C)));
+    float en = (lateral + eb * Dlen * sinphi) * rcp32(R) + 6.0f * u;
+    if (en > 8e-6f) return true;
   }
   return false;
 }

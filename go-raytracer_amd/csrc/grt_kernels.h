@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb_s
   for (; i < n; i += stride) {
     const size_t yy = i / (size_t)W, xx = i - yy * (size_t)W;
     const float* c = rgb_sum + i * 3;
-    // correctly rounded sqrt: the byte must not depend on a 1-ulp sqrt difference
-    float r = fminf(1.0f, __fsqrt_rn(c[0] * inv_samples));
-    float g = fminf(1.0f, __fsqrt_rn(c[1] * inv_samples));
-    float b = fminf(1.0f, __fsqrt_rn(c[2] * inv_samples));
+    // Correctly rounded sqrt: the byte must not depend on a 1-ulp sqrt difference.  A negative
+    // mean (only NormalMaterial produces one: (n+0.5)*0.5 with n = -1) gives NaN through
+    // Pow(c, 0.5), Min(1, NaN) = NaN, and uint8(NaN) is 0 on amd64 (CVTTSD2SL -> low byte).
+    float r = __fsqrt_rn(c[0] * inv_samples), g = __fsqrt_rn(c[1] * inv_samples), b = __fsqrt_rn(c[2] * inv_samples);
+    r = r != r ? 0.0f : fminf(1.0f, r);
+    g = g != g ? 0.0f : fminf(1.0f, g);
+    b = b != b ? 0.0f : fminf(1.0f, b);
     uint8_t* o = bgr + yy * (size_t)pitch + xx * (size_t)bpp;
     o[0] = (uint8_t)(255.99f * b);
     o[1] = (uint8_t)(255.99f * g);
@@ -164,8 +167,11 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
     b0 = grt_rng_bits24(pk, GRT_DIM_JITTER_U);
     b1 = grt_rng_bits24(pk, GRT_DIM_JITTER_V);
   }
-  f3 O, D;
-  make_primary(S, x, y, (float)b0 * (1.0f / 16777216.0f), (float)b1 * (1.0f / 16777216.0f), O, D);
+  // Rays are generated in float64 exactly as the reference does (scene.go:93-95,
+  // camera.go:37) and rounded once to FP32 for the FP32 intersection.
+  d3 O64, D64;
+  make_primary64(S64, S.W, S.H, x, y, (double)b0 * (1.0 / 16777216.0), (double)b1 * (1.0 / 16777216.0), O64, D64);
+  f3 O = mk3((float)O64.x, (float)O64.y, (float)O64.z), D = mk3((float)D64.x, (float)D64.y, (float)D64.z);
   Ray32 r;
   ray_setup(r, O, D);
   float t;
@@ -175,8 +181,6 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   else t = 0.0f;
   bool amb = force_mode == 2 || (force_mode == 0 && ambiguous32(S, r, id, t));
   if (amb) {
-    d3 O64, D64;
-    make_primary64(S64, S.W, S.H, x, y, (double)b0 * (1.0 / 16777216.0), (double)b1 * (1.0 / 16777216.0), O64, D64);
     double t64;
     id = intersect64(S64, S.n_prims, O64, D64, t64);
     nn = mk3(0.0f, 0.0f, 0.0f);

@@ -465,6 +465,10 @@ GRTO_API void grto_write_color(const double* mean_rgb, uint8_t* bgr) {
    * (color.go:52-54); scene.go:68-73: uint8(255.99*c) truncation, byte order B,G,R. */
   double c[3];
   for (int k = 0; k < 3; k++) c[k] = go_min(1.0, sqrt(mean_rgb[k]));
+  /* A negative mean (NormalMaterial: (n+0.5)*0.5 with n=-1, scene.go:275) gives NaN; Go leaves
+   * uint8(NaN) implementation-defined, amd64 yields 0 (CVTTSD2SL = 0x80000000, low byte). */
+  for (int k = 0; k < 3; k++)
+    if (isnan(c[k])) c[k] = 0.0;
   bgr[0] = (uint8_t)(255.99 * c[2]);
   bgr[1] = (uint8_t)(255.99 * c[1]);
   bgr[2] = (uint8_t)(255.99 * c[0]);

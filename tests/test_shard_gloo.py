@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo groups gather interleaved row bands into the
+frame a single process produces.  Band pixels come from the oracle here (no GPU in this
+test); the sharding/gather code under test is the product's go-raytracer_amd/shard.py."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+W, H, SPP = 40, 52, 2  # 52 rows = 6 full bands + one 4-row band: ragged on purpose
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("go-raytracer_amd")
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    from oracle import binding as ob
+
+    s = ob.OracleScene(pkg.scenes.cornell_flat(W, H))
+    rows = shard.band_rows(H, rank, world)
+    local = torch.zeros((shard.max_shard_rows(H, world), W, 3), dtype=torch.float32)
+    for i, y in enumerate(rows):  # render only the rows this rank owns
+        local[i] = torch.from_numpy(s.RenderAccum(SPP, seed=5, row_begin=y, row_end=y + 1, nthreads=1)[y].astype(np.float32))
+    frame = shard.gather_frame(local, H, rank, world, dst=0)
+    if rank == 0:
+        q.put(frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_frame_equals_single_process(pkg, ob, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = ob.OracleScene(pkg.scenes.cornell_flat(W, H)).RenderAccum(SPP, seed=5).astype(np.float32)
+    assert frame.shape == (H, W, 3) and (frame == full).all()  # exact: result independent of G
+
+
+def test_band_rows_match_library(pkg):
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    lib = pkg._capi.load()
+    for h in (1, 7, 8, 9, 52, 1080, 2160):
+        for g in (1, 2, 3, 4, 8):
+            owned = [shard.band_rows(h, r, g) for r in range(g)]
+            assert sorted(sum(owned, [])) == list(range(h))           # a partition of the rows
+            for r in range(g):
+                assert len(owned[r]) == lib.grt_shard_rows(h, r, g)
+            assert shard.max_shard_rows(h, g) == max(len(o) for o in owned)
+    assert shard.band_rows(52, 1, 2)[:9] == [8, 9, 10, 11, 12, 13, 14, 15, 24]
