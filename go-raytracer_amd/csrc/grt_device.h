@@ -76,7 +76,8 @@ struct KScene {
   int W, H, max_depth, n_prims;
   float bias;
   uint32_t seed32;
-  int n_lights, _pad;
+  int n_lights;
+  uint32_t box_mask;  // bit i set = object i is an AABB (objects 0..31)
   const float4* __restrict__ prims;
   const float4* __restrict__ mats;
   const float4* __restrict__ lights;
@@ -251,18 +252,86 @@ GRT_DEV bool refract32(f3 v, f3 n, float eta_ratio, float xi, f3& out) {
   return true;
 }
 
-// ---- one camera path as a resumable state --------------------------------------------
-struct PathState {
-  f3 O, D, thr;
-  uint32_t pkey;
-  int depth;
+// ---- one camera path as a per-lane state machine ------------------------------------------
+// Scene.trace (scene.go:237-349) is recursive with at most max_depth-1 levels and every level
+// returns (emission | 0 | weight * trace(next ray)), so a path is a throughput product and a
+// terminal radiance.  A lane holds one path; path_advance() performs ONE level for it:
+// intersect, Surface, material dispatch, and either the next ray of the same path or — when
+// the path ended — the primary ray of the lane's next sample.  The two uniforms a level needs
+// (hemisphere sample / Schlick roulette, or the pixel jitter of a fresh path) are drawn in one
+// place for every lane, so the wave does not run the RNG once per material branch.
+struct LaneState {
+  f3 O, D;       // current ray; D is unit length (primary rays are normalised at birth: only
+                 // p = O + tD and D/|D| are observable in trace(), scene.go:253-254)
+  f3 thr, acc;   // path throughput, sum of finished paths' radiance (scene.go:96)
+  uint32_t pkey; // RNG key of the current path
+  int depth;     // scene.go:237 `depth` of the ray in flight (1 = primary)
+  int s;         // sample index of the current path
 };
-GRT_DEV void path_start(const KScene& S, int x, int y, uint32_t pix_key, uint32_t sample, PathState& st) {
-  st.pkey = grt_rng_path_key(pix_key, sample);
-  make_primary(S, x, y, grt_rng_draw(st.pkey, GRT_DIM_JITTER_U), grt_rng_draw(st.pkey, GRT_DIM_JITTER_V),
-               st.O, st.D);
-  st.thr = mk3(1.0f, 1.0f, 1.0f);
-  st.depth = 1;
+
+// Ray with |D| = 1: a = inva = 1 fold away inside sphere_hit32.
+GRT_DEV void ray_setup_unit(Ray32& r, f3 O, f3 D) {
+  r.O = O;
+  r.D = D;
+  r.invD = mk3(rcp32(D.x), rcp32(D.y), rcp32(D.z));
+  r.OinvD = O * r.invD;
+  r.a = 1.0f;
+  r.inva = 1.0f;
+}
+
+// Scene.intersect with the objects in LDS: the loop is fully unrolled, every lane reads the
+// same address (an LDS broadcast, no bank conflict), the compiler hoists the reads ahead of
+// the arithmetic, and the box/sphere choice is a scalar branch on one SGPR bit mask.  (Holding
+// the 8 x 7 words in SGPRs instead overflows the 102-SGPR file: the allocator spills them to
+// VGPR lanes and pays a v_readlane per operand.)
+template <int NP>
+GRT_DEV int intersect_lds(const float4* __restrict__ tp, uint32_t box_mask, const Ray32& r, float bias, float& t_out) {
+  float tbest = 3.402823466e38f;
+  int best = -1;
+  // Records beyond n_prims are padding the host fills with a sphere of negative squared radius
+  // (never hit), so the unrolled loop carries no per-object guard.
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float4 pa = tp[2 * i], pb = tp[2 * i + 1];
+    float ht;
+    if ((box_mask >> i) & 1u)
+      ht = aabb_hit32<false>(pa, pb, r, bias, tbest);
+    else
+      ht = sphere_hit32(pa, pb, r, bias, tbest);
+    if (ht > 0.0f) {
+      best = i;
+      tbest = ht;
+    }
+  }
+  t_out = tbest;
+  return best;
+}
+
+// Surface(p) from an already fetched object record (see surface32).
+GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3& n) {
+  int bits = __float_as_int(pb.w);
+  p = fma3(r.D, t, r.O);
+  if (bits & 1) {
+    float nx = fminf((pa.x - r.O.x) * r.invD.x, (pb.x - r.O.x) * r.invD.x);
+    float ny = fminf((pa.y - r.O.y) * r.invD.y, (pb.y - r.O.y) * r.invD.y);
+    float nz = fminf((pa.z - r.O.z) * r.invD.z, (pb.z - r.O.z) * r.invD.z);
+    const bool ax0 = (nx >= ny) & (nx >= nz), ax1 = !ax0 & (ny >= nz), ax2 = !ax0 & !ax1;
+    p.x = ax0 ? (r.D.x > 0.0f ? pa.x : pb.x) : p.x;
+    p.y = ax1 ? (r.D.y > 0.0f ? pa.y : pb.y) : p.y;
+    p.z = ax2 ? (r.D.z > 0.0f ? pa.z : pb.z) : p.z;
+    const float eps = 1e-4f;  // aabb.go:56; the cascade of aabb.go:57-70 without branches
+    const bool x0 = p.x - pa.x < eps, x1 = pb.x - p.x < eps, y0 = p.y - pa.y < eps, y1 = pb.y - p.y < eps;
+    const bool z0 = p.z - pa.z < eps, z1 = pb.z - p.z < eps;
+    const bool cx = x0 | x1, cy = !cx & (y0 | y1), cz = !cx & !(y0 | y1) & (z0 | z1);
+    n.x = cx ? (x0 ? -1.0f : 1.0f) : 0.0f;
+    n.y = cy ? (y0 ? -1.0f : 1.0f) : 0.0f;
+    n.z = cz ? (z0 ? -1.0f : 1.0f) : 0.0f;
+  } else {
+    f3 d = mk3(p.x - pa.x, p.y - pa.y, p.z - pa.z);
+    float s = rsq32(dot3(d, d));
+    n = d * (pa.w < 0.0f ? -s : s);
+  }
+  return bits >> 8;
 }
 
 // Direct illumination of the plain "diffuse" material (scene.go:322-346): every light is a
@@ -297,63 +366,105 @@ GRT_DEV f3 direct_light32(const KScene& S, f3 p, f3 n, f3 color) {
   return result;
 }
 
-// One level of Scene.trace (scene.go:237-349) in throughput form.  Returns true when the
-// path ended; `radiance` then holds its contribution (already multiplied by the path
-// throughput).  Otherwise st holds the next ray.  n_rays counts intersect() calls.
-GRT_DEV bool path_step(const KScene& S, PathState& st, f3& radiance, int& n_rays) {
+// Birth of sample `s` of the lane's pixel: scene.go:93-95 with the jitter (u1,u2) supplied.
+GRT_DEV void primary_unit(const KScene& S, float fx, float fy, float u1, float u2, f3& O, f3& D) {
+  float u = (fx + u1) * (1.0f / (float)S.W);
+  float v = (fy + u2) * (1.0f / (float)S.H);
+  O = mk3(S.cam.ox, S.cam.oy, S.cam.oz);
+  D = unit3(mk3(fmaf(S.cam.vx, v, fmaf(S.cam.hx, u, S.cam.lx)), fmaf(S.cam.vy, v, fmaf(S.cam.hy, u, S.cam.ly)),
+                fmaf(S.cam.vz, v, fmaf(S.cam.hz, u, S.cam.lz))));
+}
+GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, int s, LaneState& L) {
+  L.s = s;
+  L.pkey = grt_rng_path_key(pix_key, (uint32_t)s);
+  primary_unit(S, fx, fy, grt_rng_draw(L.pkey, GRT_DIM_JITTER_U), grt_rng_draw(L.pkey, GRT_DIM_JITTER_V), L.O, L.D);
+  L.thr = mk3(1.0f, 1.0f, 1.0f);
+  L.acc = mk3(0.0f, 0.0f, 0.0f);
+  L.depth = 1;
+}
+
+// One level of trace() for one lane.  NP > 0: tp (objects) and tm (materials) are LDS copies
+// and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
+// arrays of S and the loop runs over S.n_prims.  `alive` turns false when the lane has finished
+// sample s_end-1.  n_rays counts intersect() calls (scene.go:242).
+template <int NP, bool RELOAD = false>
+GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
+                          uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays) {
+  // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
+  // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
+  if (RELOAD) asm volatile("" ::: "memory");
   Ray32 r;
-  ray_setup(r, st.O, st.D);
+  ray_setup_unit(r, L.O, L.D);
   float t;
-  n_rays++;
-  int id = intersect32(S, r, t);                    // scene.go:242
-  radiance = mk3(0.0f, 0.0f, 0.0f);
-  if (id < 0) return true;                          // scene.go:244-250
+  int id;
+  if (__builtin_expect(__any(ray_has_zero(r)), 0))
+    id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
+  else if (NP > 0)
+    id = intersect_lds<NP>(tp, S.box_mask, r, S.bias, t);
+  else
+    id = intersect32_t<false>(S, r, t);
+  n_rays++;                                         // scene.go:242
+  const bool hit = id >= 0;                         // scene.go:244
+  const int idc = hit ? id : 0;
+  const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];
   f3 p, n;
-  int m = surface32(S, id, r, t, p, n);             // scene.go:254-255
-  float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
-  int flags = __float_as_int(m1.w);
-  f3 color = mk3(m0.x, m0.y, m0.z);
-  if (flags & GRT_MAT_NORMAL) {                     // scene.go:274-276
-    radiance = st.thr * mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);
-    return true;
+  const int m = surface_rec(pa, pb, r, t, p, n);    // scene.go:254-255
+  const float4 m0 = tm[2 * m], m1 = tm[2 * m + 1];
+  const int flags = __float_as_int(m1.w);
+  const f3 color = mk3(m0.x, m0.y, m0.z);
+  // material priority of scene.go:274-305: Normal, Emittance, Lambert, Reflectivity, Transparent, diffuse
+  const bool is_normal = hit & ((flags & GRT_MAT_NORMAL) != 0);
+  const bool is_emit = hit & !is_normal & (m1.z > 0.0f);
+  const bool rest = hit & !is_normal & !is_emit;
+  const bool is_lamb = rest & ((flags & GRT_MAT_LAMBERT) != 0);
+  const bool is_metal = rest & !is_lamb & (m1.x > 0.0f);
+  const bool is_glass = rest & !is_lamb & !is_metal & ((flags & GRT_MAT_TRANSPARENT) != 0);
+  const bool is_diff = rest & !is_lamb & !is_metal & !is_glass;
+  f3 rad = mk3(0.0f, 0.0f, 0.0f);
+  if (is_emit) rad = color * m1.z;                                                              // scene.go:279
+  if (is_normal) rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);      // scene.go:275
+  if (__builtin_expect(__any(is_diff), 0)) {
+    if (is_diff) rad = direct_light32(S, p, n, color);                                           // scene.go:322-346
   }
-  if (m1.z > 0.0f) {                                // scene.go:278-279
-    radiance = st.thr * (color * m1.z);
-    return true;
-  }
-  const bool scatters = (flags & (GRT_MAT_LAMBERT | GRT_MAT_TRANSPARENT)) | (m1.x > 0.0f);
-  if (scatters && st.depth + 1 >= S.max_depth) return true;  // the recursive call returns black (scene.go:238)
-  if (flags & GRT_MAT_LAMBERT) {                    // scene.go:280-286
-    f3 d = sample_hemi32(n, grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 0)),
-                         grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 1)));
-    st.thr = st.thr * color;
-    st.O = p;
-    st.D = d;
-  } else if (m1.x > 0.0f) {                         // scene.go:287-294
-    f3 incident = r.D * rsq32(r.a);
-    f3 refl = reflect32(incident, n);
+  // a scattering material at the last level: the recursive call returns black (scene.go:238)
+  bool term = !hit | is_normal | is_emit | is_diff | (L.depth + 1 >= S.max_depth);
+  f3 dir = n;
+  if (is_metal & !term) {                           // scene.go:287-294
+    dir = reflect32(r.D, n);
     if (m1.y != 0.0f) {
-      f3 fz = sample_hemi32(n, grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 0)),
-                            grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 1)));
-      refl = fma3(fz, m1.y, refl);
+      f3 fz = sample_hemi32(n, grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 0)), grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 1)));
+      dir = fma3(fz, m1.y, dir);
+      if (!(dot3(dir, n) > 0.0f)) term = true;      // scene.go:291: no ray, black
+      else dir = unit3(dir);                        // keep |D| = 1 (direction unchanged)
     }
-    if (!(dot3(refl, n) > 0.0f)) return true;
-    st.thr = st.thr * (color * m1.x);
-    st.O = p;
-    st.D = refl;
-  } else if (flags & GRT_MAT_TRANSPARENT) {         // scene.go:295-304
-    f3 incident = r.D * rsq32(r.a);
-    f3 dir;
-    if (!refract32(incident, n, rcp32(m0.w), grt_rng_draw(st.pkey, GRT_DIM_HIT(st.depth, 2)), dir))
-      dir = reflect32(incident, n);
-    st.O = p;
-    st.D = dir;
-  } else {                                          // scene.go:305-347
-    radiance = st.thr * direct_light32(S, p, n, color);
-    return true;
   }
-  st.depth++;
-  return false;
+  L.acc = mk3(fmaf(L.thr.x, rad.x, L.acc.x), fmaf(L.thr.y, rad.y, L.acc.y), fmaf(L.thr.z, rad.z, L.acc.z));
+  if (term) {                                       // next sample of this pixel (scene.go:92)
+    L.s++;
+    alive = L.s < s_end;
+    L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
+    L.depth = 0;
+    L.thr = mk3(1.0f, 1.0f, 1.0f);
+  }
+  const uint32_t base = term ? GRT_DIM_JITTER_U : GRT_DIM_HIT(L.depth, 0);
+  const float u1 = grt_rng_draw(L.pkey, base), u2 = grt_rng_draw(L.pkey, base + 1u);
+  if (term) {
+    primary_unit(S, fx, fy, u1, u2, L.O, L.D);
+  } else {
+    L.O = p;
+    if (is_lamb) {                                  // scene.go:280-286
+      L.D = sample_hemi32(n, u1, u2);
+      L.thr = L.thr * color;
+    } else if (is_metal) {
+      L.D = dir;
+      L.thr = L.thr * (color * m1.x);
+    } else {                                        // scene.go:295-304; u1 is the roulette draw
+      f3 d;
+      if (!refract32(r.D, n, rcp32(m0.w), u1, d)) d = reflect32(r.D, n);
+      L.D = d;
+    }
+  }
+  L.depth++;
 }
 
 // ======================================================================================

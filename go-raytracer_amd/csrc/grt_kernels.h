@@ -27,13 +27,47 @@ GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
   return s;
 }
 
+// Scene tables for the per-lane record gathers of path_advance: objects and materials are
+// copied to LDS once per workgroup (NP > 0) and the objects are also loaded into registers
+// for the unrolled intersect loop.
+#define GRT_FAST_PRIMS 8
+
+template <int NP>
+struct SceneTables {
+  const float4* tp;
+  const float4* tm;
+};
+
+// The host pads the staged arrays to GRT_FAST_PRIMS records, so the copies are unconditional.
+template <int NP>
+GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
+  if (NP > 0) {
+    // [0, 2NP) objects, [2NP, 4NP) materials (a scene never has more materials than objects
+    // after de-duplication; the host checks n_mats <= NP before choosing this kernel)
+    for (int i = threadIdx.x; i < 2 * NP; i += blockDim.x) {
+      lds[i] = S.prims[i];
+      lds[2 * NP + i] = S.mats[i];
+    }
+    __syncthreads();
+    T.tp = lds;
+    T.tm = lds + 2 * NP;
+  } else {
+    T.tp = S.prims;
+    T.tm = S.mats;
+  }
+}
+
 // One wave = one (tile, chunk) work item; one lane = one pixel.  Each lane runs its pixel's
 // samples back to back: when its path ends it adds the radiance and starts the next sample
 // in the same loop iteration, so every iteration of the wave-wide loop does one intersect()
 // for every lane that still has samples left — terminated paths never leave idle lanes
 // behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
+template <int NP, bool RELOAD = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
+  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  SceneTables<NP> T;
+  load_tables<NP>(S, lds, T);
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
@@ -44,36 +78,23 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
   const int lrow = lband * 8 + (lane >> 3);
   const bool valid = (x < S.W) & (y < S.H);
 
-  int s = chunk * J.chunk_spp;
-  const int s_end = min(s + J.chunk_spp, J.spp);
+  const int s0 = chunk * J.chunk_spp;
+  const int s_end = min(s0 + J.chunk_spp, J.spp);
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  const float fx = (float)x, fy = (float)y;
 
-  f3 acc = mk3(0.0f, 0.0f, 0.0f);
   int n_rays = 0;
-  bool alive = valid & (s < s_end);
-  PathState st;
-  st.O = st.D = st.thr = mk3(0.0f, 0.0f, 1.0f);
-  st.pkey = 0;
-  st.depth = 1;
-  if (alive) path_start(S, x, y, pix_key, (uint32_t)s, st);
+  bool alive = valid & (s0 < s_end);
+  LaneState L;
+  lane_begin(S, fx, fy, pix_key, s0, L);
   while (__any(alive)) {
-    if (alive) {
-      f3 rad;
-      if (path_step(S, st, rad, n_rays)) {
-        acc = acc + rad;  // scene.go:96
-        ++s;
-        if (s < s_end)
-          path_start(S, x, y, pix_key, (uint32_t)s, st);
-        else
-          alive = false;
-      }
-    }
+    if (alive) path_advance<NP, RELOAD>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays);
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
-    o[0] = acc.x;
-    o[1] = acc.y;
-    o[2] = acc.z;
+    o[0] = L.acc.x;
+    o[1] = L.acc.y;
+    o[2] = L.acc.z;
   }
   if (ray_count) {
     unsigned long long tot = wave_sum_u32((unsigned)n_rays);
@@ -117,34 +138,33 @@ __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb_s
   }
 }
 
-// One thread per (pixel, sample): rgb = trace(), n_rays = intersect() calls.
+// One thread per (pixel, sample): rgb = trace(), n_rays = intersect() calls.  Same
+// path_advance as k_pathtrace, stopped after one sample.
+template <int NP>
 __global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __restrict__ pixel_xy, int n_pixels,
                                                        int samples, float* __restrict__ rgb,
                                                        int* __restrict__ n_rays_out) {
+  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  SceneTables<NP> T;
+  load_tables<NP>(S, lds, T);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < (size_t)n_pixels * (size_t)samples;
   const size_t j = valid ? i : 0;
   const int pi = (int)(j / (size_t)samples), s = (int)(j % (size_t)samples);
   const int x = pixel_xy[2 * pi], y = pixel_xy[2 * pi + 1];
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
-  PathState st;
-  path_start(S, x, y, pix_key, (uint32_t)s, st);
-  f3 rad = mk3(0.0f, 0.0f, 0.0f);
+  const float fx = (float)x, fy = (float)y;
+  LaneState L;
+  lane_begin(S, fx, fy, pix_key, s, L);
   int n_rays = 0;
   bool alive = valid;
   while (__any(alive)) {
-    if (alive) {
-      f3 r;
-      if (path_step(S, st, r, n_rays)) {
-        rad = r;
-        alive = false;
-      }
-    }
+    if (alive) path_advance<NP>(S, T.tp, T.tm, fx, fy, pix_key, s + 1, L, alive, n_rays);
   }
   if (valid) {
-    rgb[i * 3 + 0] = rad.x;
-    rgb[i * 3 + 1] = rad.y;
-    rgb[i * 3 + 2] = rad.z;
+    rgb[i * 3 + 0] = L.acc.x;
+    rgb[i * 3 + 1] = L.acc.y;
+    rgb[i * 3 + 2] = L.acc.z;
     if (n_rays_out) n_rays_out[i] = n_rays;
   }
 }

@@ -46,11 +46,12 @@ GRT_HD double grt_rng_draw64(uint32_t path_key, uint32_t dim) {
 }
 
 // Dimension layout of one camera path: 0,1 = pixel jitter (scene.go:93-94); the hit at depth
-// d (1-based, scene.go:237) owns 2+3(d-1)+{0,1} for SampleHemisphereNormal's two draws in
-// call order (vec3.go:203-204) and +2 for Refract's roulette (vec3.go:152).
+// d (1-based, scene.go:237) owns 2+2(d-1)+{0,1}: SampleHemisphereNormal's two draws in call
+// order (vec3.go:203-204) for Lambert / rough metal, or — the material branches of trace() are
+// exclusive — Refract's roulette draw (vec3.go:152) in slot 0.
 #define GRT_DIM_JITTER_U 0u
 #define GRT_DIM_JITTER_V 1u
-#define GRT_DIM_HIT(depth, k) (2u + 3u * (uint32_t)((depth)-1) + (uint32_t)(k))
+#define GRT_DIM_HIT(depth, k) (2u + 2u * (uint32_t)((depth)-1) + (uint32_t)(k))
 
 // Photon walks (scene.go:140-165, 354-424) use pixel = photon index, sample = map id:
 // 0,1 = emission direction; bounce d owns 2+4(d-1)+{0,1} hemisphere, +2 Refract, +3 roulette.

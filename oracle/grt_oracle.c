@@ -124,13 +124,13 @@ GRTO_API double grto_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uin
   return rng_draw(rng_path_key(rng_pixel_key(rng_seed32(seed), pixel), sample), dim);
 }
 
-/* Dimension layout of one camera path: 0,1 = pixel jitter (scene.go:93-94);
- * the hit at depth d (1-based, scene.go:237) owns 2+3(d-1)+{0,1} for
- * SampleHemisphereNormal's two draws in call order (vec3.go:203-204) and +2 for Refract's
- * roulette draw (vec3.go:152). */
+/* Dimension layout of one camera path: 0,1 = pixel jitter (scene.go:93-94); the hit at depth d
+ * (1-based, scene.go:237) owns 2+2(d-1)+{0,1}: SampleHemisphereNormal's two draws in call
+ * order (vec3.go:203-204), or - the material branches of trace() are exclusive - Refract's
+ * roulette draw (vec3.go:152) in slot 0. */
 #define DIM_JITTER_U 0u
 #define DIM_JITTER_V 1u
-#define DIM_HIT(depth, k) (2u + 3u * (uint32_t)((depth)-1) + (uint32_t)(k))
+#define DIM_HIT(depth, k) (2u + 2u * (uint32_t)((depth)-1) + (uint32_t)(k))
 
 /* ------------------------------------------------------------------------------------
  * Camera (pkg/tracer/camera.go)
@@ -402,7 +402,7 @@ static v3 trace(const grto_scene* s, ray r, int depth, pathctx* px) {
   } else if (m->transparent) { /* :295-304 */
     double refrRatio = 1.0 / m->refr_index;
     v3 dir;
-    int ok = refract(incident, n, refrRatio, rng_draw(px->path_key, DIM_HIT(depth, 2)), &dir);
+    int ok = refract(incident, n, refrRatio, rng_draw(px->path_key, DIM_HIT(depth, 0)), &dir);
     if (!ok) dir = reflect(incident, n);
     ray r2 = {p, dir};
     result = v_plus(result, trace(s, r2, depth + 1, px));
