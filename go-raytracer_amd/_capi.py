@@ -74,7 +74,9 @@ PROTOTYPES = {
     "grt_photon_read": (C.c_int, [_vp, _vp, _vp, _vp]),
     "grt_photon_load": (C.c_int, [P(Opts), _vp, _vp, _vp, C.c_int32, P(_vp)]),
     "grt_photon_gather": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp]),
-    "grt_photon_gather_dev": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp]),
+    "grt_photon_gather_dev": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp, _vp]),
+    "grt_photon_gather_workspace_bytes": (C.c_uint64, [C.c_int32]),
+    "grt_photon_emitted": (C.c_uint64, [_vp]),
     "grt_photon_free": (None, [_vp]),
     "grt_rng_u01": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grt_last_ray_count": (C.c_uint64, []),

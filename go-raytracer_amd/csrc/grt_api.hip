@@ -47,24 +47,6 @@ GRT_API double grt_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint3
 }
 
 // ---- scene staging ---------------------------------------------------------------------
-struct DeviceScene {
-  float4* prims = nullptr;
-  float4* mats = nullptr;
-  float4* lights = nullptr;
-  double* prims64 = nullptr;
-};
-
-struct grt_scene {
-  grt_scene_desc d;
-  std::vector<grt_prim> prims;
-  std::vector<grt_material> mats;
-  std::vector<int> lights;    // scene.go:42-46
-  std::vector<int> tobjects;  // scene.go:48-50
-  double light_area = 0.0;
-  std::mutex mu;
-  std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
-};
-
 static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_prims, const grt_material* mats,
                           int n_mats) {
   if (!d) return grt_fail(GRT_EINVAL, "grt_scene_create: desc is NULL");
@@ -144,7 +126,7 @@ static int stage(grt_scene* s, DeviceScene& out) {
   for (size_t i = 0; i < np; ++i) {
     const grt_prim& p = s->prims[i];
     const grt_material& m = s->mats[p.material];
-    int bits = (p.kind == GRT_KIND_AABB ? 1 : 0) | (m.emittance > 0 ? 2 : 0) | (p.material << 8);
+    int bits = (p.kind == GRT_KIND_AABB ? 1 : 0) | (m.emittance > 0 ? 2 : 0) | (m.transparent ? 4 : 0) | (p.material << 8);
     float w;
     memcpy(&w, &bits, 4);
     hp[2 * i] = make_float4((float)p.a[0], (float)p.a[1], (float)p.a[2], (float)p.radius);

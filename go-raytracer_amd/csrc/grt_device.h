@@ -60,7 +60,8 @@ GRT_DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 // ---- scene as the kernels see it -----------------------------------------------------
 // prims[2i]   = (a.x, a.y, a.z, radius)          sphere centre | box MinBound
 // prims[2i+1] = (b.x, b.y, b.z, bits)            box MaxBound  | sphere: b.x = radius^2
-//               bits (int): bit0 kind (1 = AABB), bit1 emissive (Emittance > 0), mat << 8
+//               bits (int): bit0 kind (1 = AABB), bit1 emissive (Emittance > 0), bit2 transparent,
+//               mat << 8
 // mats[2m]    = (r, g, b, refr_index)
 // mats[2m+1]  = (reflectivity, roughness, emittance, flags)   flags: 1 transparent,
 //               2 lambert, 4 normal

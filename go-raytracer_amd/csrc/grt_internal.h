@@ -4,6 +4,10 @@
 #include <stdarg.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "../../include/grt.h"
 
 // The linear-scan kernels (the reference's own algorithm, scene.go:173) read every object
@@ -17,6 +21,24 @@ int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)
     hipError_t e_ = (expr);                                                             \
     if (e_ != hipSuccess) return grt_fail(GRT_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+struct DeviceScene {
+  float4* prims = nullptr;
+  float4* mats = nullptr;
+  float4* lights = nullptr;
+  double* prims64 = nullptr;
+};
+
+struct grt_scene {
+  grt_scene_desc d;
+  std::vector<grt_prim> prims;
+  std::vector<grt_material> mats;
+  std::vector<int> lights;    // scene.go:42-46
+  std::vector<int> tobjects;  // scene.go:48-50
+  double light_area = 0.0;
+  std::mutex mu;
+  std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
+};
 
 struct KScene;
 // Stages `s` on the current device if needed and fills the kernel-side view.

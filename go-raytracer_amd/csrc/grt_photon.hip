@@ -1,25 +1,641 @@
-// grt_photon.hip — photon map emission, kd-tree build and kNN gather (config C4).
+// grt_photon.hip — photon map emission, kd-tree and k-nearest-photon radiance gather (config C4).
+//
+//   k_photon_trace   mapPhotons' emission loop body + tracePhotons   scene.go:152-160, 354-424
+//                    + Store's direction quantisation                photon_mapping.go:165-193
+//   k_photon_scatter ordered compaction of the stored photons + ScalePhotonPower's scale
+//                    (photon_mapping.go:197-206)
+//   balance()        kdtree.New(list, true) (photon_mapping.go:207): a left-balanced kd-tree in
+//                    implicit heap order (children of node i are 2i and 2i+1, no pointers)
+//   k_knn_radius     NearestSet + NKeeper(k) (photon_mapping.go:131-133): squared distance of
+//                    the k-th nearest photon, per query
+//   k_gather         the loop of IrradianceEst (photon_mapping.go:138-161)
+//
+// PARITY UNPINNED for this path: the reference never runs it and the tree is
+// gonum's.  The definitions used where the source leaves room are those of
+// oracle/grt_oracle_photon.h (ties at the k-th distance all kept; r2 = largest accepted d^2).
+//
+// Emission is one thread per emitted photon, keyed by its emission index, so the stored set
+// equals what the reference's sequential loop would store with the same uniforms: the map is
+// the first `max` stores in emission order (flag -> exclusive scan -> scatter).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <vector>
 
 #include "../../include/grt.h"
+#include "grt_device.h"
 #include "grt_internal.h"
 
 #define GRT_API extern "C" __attribute__((visibility("default")))
+#define PI_F 3.14159265358979323846f
 
-GRT_API int grt_photon_build(grt_scene*, const grt_opts*, int32_t, int32_t, grt_pmap**) {
-  return grt_fail(GRT_EINVAL, "grt_photon_build: not built yet");
+// ---- photon record in HBM (kd-tree order, 1-based; 28 B per photon) ------------------------
+//   pos4[i]  = (x, y, z, bits)   bits: split axis (2 bits) | theta << 8 | phi << 16
+//   pow3[3i] = power r, g, b     (already scaled by 1000/max)
+struct grt_pmap {
+  int n = 0, max = 0, device = 0;
+  uint64_t emitted = 0;
+  float4* d_pos4 = nullptr;  // [n+1]
+  float* d_pow3 = nullptr;   // [3(n+1)]
+  float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
+  std::vector<int> order;    // tree slot -> storage (emission) index, for grt_photon_read
+};
+
+// ---- emission ---------------------------------------------------------------------------------
+// intersect over the transparent objects only (scene.tObjects, scene.go:48-50,360)
+GRT_DEV bool hits_transparent(const KScene& S, const Ray32& r, bool careful) {
+  float tbest = 3.402823466e38f;
+  bool hit = false;
+  for (int i = 0; i < S.n_prims; ++i) {
+    float4 pa = S.prims[2 * i], pb = S.prims[2 * i + 1];
+    int bits = __float_as_int(pb.w);
+    if (!(bits & 4)) continue;
+    float ht;
+    if (bits & 1)
+      ht = careful ? aabb_hit32<true>(pa, pb, r, S.bias, tbest) : aabb_hit32<false>(pa, pb, r, S.bias, tbest);
+    else
+      ht = sphere_hit32(pa, pb, r, S.bias, tbest);
+    if (ht > 0.0f) {
+      hit = true;
+      tbest = ht;
+    }
+  }
+  return hit;
 }
-GRT_API int32_t grt_photon_count(const grt_pmap*) { return 0; }
-GRT_API int grt_photon_read(const grt_pmap*, float*, float*, uint8_t*) {
-  return grt_fail(GRT_EINVAL, "grt_photon_read: not built yet");
+
+// Store's quantisation (photon_mapping.go:177-191); Go's int() truncates toward zero.
+GRT_DEV int quantize_dir(f3 d) {
+  int theta = (int)(acosf(fminf(fmaxf(d.z, -1.0f), 1.0f)) * (256.0f / PI_F));
+  theta = theta > 255 ? 255 : theta;
+  int phi = (int)(atan2f(d.y, d.x) * (256.0f / (2.0f * PI_F)));
+  phi = phi > 255 ? 255 : (phi < 0 ? phi + 256 : phi);
+  return (theta << 8) | ((phi & 255) << 16);
 }
-GRT_API int grt_photon_load(const grt_opts*, const float*, const float*, const uint8_t*, int32_t, grt_pmap**) {
-  return grt_fail(GRT_EINVAL, "grt_photon_load: not built yet");
+
+__global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos, float3 power0, int caustics,
+                                                      unsigned long long first, int n_emit, int* __restrict__ flag,
+                                                      float4* __restrict__ rec_pos, float4* __restrict__ rec_pow) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n_emit;
+  const unsigned long long e = first + (unsigned long long)(valid ? i : 0);
+  const uint32_t key = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)e),
+                                        (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
+  f3 O = mk3(light_pos.x, light_pos.y, light_pos.z);  // l.Pos(), scene.go:149
+  f3 D = sample_hemi32(mk3(0.0f, -1.0f, 0.0f), grt_rng_draw(key, GRT_PDIM_EMIT_U), grt_rng_draw(key, GRT_PDIM_EMIT_V));
+  f3 power = mk3(power0.x, power0.y, power0.z);
+  bool alive = valid, stored = false;
+  f3 sp = mk3(0, 0, 0), spow = mk3(0, 0, 0);
+  int sbits = 0;
+  for (int depth = 1; depth < S.max_depth; ++depth) {  // scene.go:355
+    if (!__any(alive)) break;
+    if (alive) {
+      Ray32 r;
+      ray_setup(r, O, D);
+      const bool careful = __any(ray_has_zero(r));
+      if (caustics && depth == 1 && !hits_transparent(S, r, careful)) alive = false;  // scene.go:359-363
+      if (alive) {
+        float t;
+        int id = careful ? intersect32_t<true>(S, r, t) : intersect32_t<false>(S, r, t);  // scene.go:365
+        if (id < 0) {
+          alive = false;
+        } else {
+          f3 p, n;
+          int m = surface32(S, id, r, t, p, n);
+          float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
+          int flags = __float_as_int(m1.w);
+          f3 incident = r.D * rsq32(r.a);  // scene.go:371
+          f3 f = mk3(m0.x, m0.y, m0.z);
+          if (caustics && depth == 1 && !(flags & GRT_MAT_TRANSPARENT)) {  // scene.go:375
+            alive = false;
+          } else if ((flags & GRT_MAT_NORMAL) || m1.z > 0.0f || (flags & GRT_MAT_LAMBERT)) {
+            alive = false;  // scene.go:391-396: Normal / light stop; Lambert drops the photon
+          } else if (m1.x > 0.0f) {  // scene.go:397-402
+            f3 on = dot3(n, incident) >= 0.0f ? -n : n;
+            f3 refl = reflect32(incident, n);
+            if (m1.y != 0.0f)
+              refl = fma3(sample_hemi32(on, grt_rng_draw(key, GRT_PDIM_HIT(depth, 0)), grt_rng_draw(key, GRT_PDIM_HIT(depth, 1))),
+                          m1.y, refl);
+            O = p, D = refl, power = power * f;
+          } else if (flags & GRT_MAT_TRANSPARENT) {  // scene.go:403-412
+            f3 dir;
+            if (!refract32(incident, n, rcp32(m0.w), grt_rng_draw(key, GRT_PDIM_HIT(depth, 2)), dir)) dir = reflect32(incident, n);
+            O = p, D = dir;
+          } else {
+            const float rrp = (f.x + f.y + f.z) * (1.0f / 3.0f);  // scene.go:388
+            if (grt_rng_draw(key, GRT_PDIM_HIT(depth, 3)) < rrp) {  // scene.go:414-417
+              stored = true;
+              sp = p;
+              spow = (f * power) * (1.0f / (1.0f - rrp));
+              sbits = quantize_dir(incident);
+              alive = false;
+            } else {  // scene.go:418-422
+              O = p;
+              D = sample_hemi32(n, grt_rng_draw(key, GRT_PDIM_HIT(depth, 0)), grt_rng_draw(key, GRT_PDIM_HIT(depth, 1)));
+              power = (f * power) * (1.0f / rrp);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (valid) {
+    flag[i] = stored ? 1 : 0;
+    if (stored) {
+      rec_pos[i] = make_float4(sp.x, sp.y, sp.z, __int_as_float(sbits));
+      rec_pow[i] = make_float4(spow.x, spow.y, spow.z, 0.0f);
+    }
+  }
 }
-GRT_API int grt_photon_gather(const grt_pmap*, const float*, const float*, int32_t, float, int32_t, float*) {
-  return grt_fail(GRT_EINVAL, "grt_photon_gather: not built yet");
+
+// Stores in emission order: photon i of the batch goes to slot base + scan[i] while the map has
+// room (Store's cap, photon_mapping.go:166).  last_emit = emission index of the store that filled it.
+__global__ __launch_bounds__(256) void k_photon_scatter(const int* __restrict__ flag, const int* __restrict__ scan, int n_emit,
+                                                        int base, int max, float scale, const float4* __restrict__ rec_pos,
+                                                        const float4* __restrict__ rec_pow, float4* __restrict__ out_pos,
+                                                        float4* __restrict__ out_pow, int* __restrict__ last_emit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_emit || !flag[i]) return;
+  const int slot = base + scan[i];
+  if (slot >= max) return;
+  float4 pw = rec_pow[i];
+  out_pos[slot] = rec_pos[i];
+  out_pow[slot] = make_float4(pw.x * scale, pw.y * scale, pw.z * scale, 0.0f);
+  if (slot == max - 1) *last_emit = i;
 }
-GRT_API int grt_photon_gather_dev(const grt_pmap*, const float*, const float*, int32_t, float, int32_t, float*, void*) {
-  return grt_fail(GRT_EINVAL, "grt_photon_gather_dev: not built yet");
+
+// ---- left-balanced kd-tree (host) -----------------------------------------------------------
+struct HostPhoton {
+  float p[3];
+  float pw[3];
+  int bits, src;
+};
+static void balance(std::vector<HostPhoton>& ph, std::vector<int>& idx, int lo, int hi, size_t node, std::vector<int>& heap,
+                    std::vector<uint8_t>& axis_of, int par_depth) {
+  const int n = hi - lo;
+  if (n <= 0) return;
+  // split axis: largest extent of the segment
+  float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = lo; i < hi; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = ph[idx[i]].p[k];
+      mn[k] = std::min(mn[k], v), mx[k] = std::max(mx[k], v);
+    }
+  int ax = 0;
+  if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+  if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+  // size of the left subtree of a left-balanced tree with n nodes
+  int m = 1;
+  while (4 * m <= n) m *= 2;
+  const int left = (3 * m <= n) ? 2 * m - 1 : n - m;
+  auto cmp = [&](int a, int b) {
+    float x = ph[a].p[ax], y = ph[b].p[ax];
+    return x < y || (x == y && a < b);
+  };
+  std::nth_element(idx.begin() + lo, idx.begin() + lo + left, idx.begin() + hi, cmp);
+  heap[node] = idx[lo + left];
+  axis_of[node] = (uint8_t)ax;
+  if (par_depth > 0 && n > 4096) {
+    auto fut = std::async(std::launch::async, [&, lo, left, node, par_depth] {
+      balance(ph, idx, lo, lo + left, 2 * node, heap, axis_of, par_depth - 1);
+    });
+    balance(ph, idx, lo + left + 1, hi, 2 * node + 1, heap, axis_of, par_depth - 1);
+    fut.get();
+  } else {
+    balance(ph, idx, lo, lo + left, 2 * node, heap, axis_of, 0);
+    balance(ph, idx, lo + left + 1, hi, 2 * node + 1, heap, axis_of, 0);
+  }
 }
-GRT_API void grt_photon_free(grt_pmap*) {}
+
+static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
+  const int n = (int)ph.size();
+  std::vector<int> idx(n), heap((size_t)n + 1, -1);
+  std::vector<uint8_t> axis_of((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  balance(ph, idx, 0, n, 1, heap, axis_of, 4);
+  std::vector<float4> pos4((size_t)n + 1);
+  std::vector<float> pow3(3 * ((size_t)n + 1), 0.0f);
+  pm->order.assign((size_t)n + 1, -1);
+  pos4[0] = make_float4(0, 0, 0, 0);
+  for (int i = 1; i <= n; ++i) {
+    const HostPhoton& h = ph[heap[i]];
+    int bits = (h.bits & ~3) | axis_of[i];
+    float w;
+    memcpy(&w, &bits, 4);
+    pos4[i] = make_float4(h.p[0], h.p[1], h.p[2], w);
+    pow3[3 * (size_t)i] = h.pw[0], pow3[3 * (size_t)i + 1] = h.pw[1], pow3[3 * (size_t)i + 2] = h.pw[2];
+    pm->order[i] = h.src;
+  }
+  std::vector<float> lut(4 * 256);
+  for (int i = 0; i < 256; ++i) {  // photon_mapping.go:105-111
+    double angle = (double)i * (1.0 / 256.0) * M_PI;
+    lut[i] = (float)cos(angle), lut[256 + i] = (float)sin(angle);
+    lut[512 + i] = (float)cos(2.0 * angle), lut[768 + i] = (float)sin(2.0 * angle);
+  }
+  pm->n = n;
+  GRT_HIP(hipMalloc(&pm->d_pos4, pos4.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&pm->d_pow3, pow3.size() * sizeof(float)));
+  GRT_HIP(hipMalloc(&pm->d_lut, lut.size() * sizeof(float)));
+  GRT_HIP(hipMemcpy(pm->d_pos4, pos4.data(), pos4.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(pm->d_pow3, pow3.data(), pow3.size() * sizeof(float), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(pm->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+  return GRT_OK;
+}
+
+static int pick_device(const grt_opts* o, int* dev) {
+  int ndev = grt_device_count();
+  if (ndev <= 0) return grt_fail(GRT_ENODEV, "no HIP device visible");
+  *dev = o ? o->first_device : 0;
+  if (*dev < 0 || *dev >= ndev) return grt_fail(GRT_ENODEV, "device %d requested, %d visible", *dev, ndev);
+  GRT_HIP(hipSetDevice(*dev));
+  return GRT_OK;
+}
+
+GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) {
+  if (!s || !out || max_photons <= 0) return grt_fail(GRT_EINVAL, "grt_photon_build: bad argument");
+  if (s->lights.empty()) return grt_fail(GRT_EINVAL, "grt_photon_build: the scene has no light (Emittance > 0)");
+  int dev;
+  int rc = pick_device(o, &dev);
+  if (rc) return rc;
+  KScene ks;
+  rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  const int BATCH_MAX = 1 << 23;
+  int *d_flag = nullptr, *d_scan = nullptr, *d_last = nullptr;
+  float4 *d_rpos = nullptr, *d_rpow = nullptr, *d_opos = nullptr, *d_opow = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  std::vector<HostPhoton> ph;
+  grt_pmap* pm = new grt_pmap;
+  pm->max = max_photons;
+  pm->device = dev;
+  rc = GRT_OK;
+#define PTRY(x)                                                                     \
+  {                                                                                 \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      rc = grt_fail(GRT_EHIP, "%s: %s", #x, hipGetErrorString(e_));                 \
+      break;                                                                        \
+    }                                                                               \
+  }
+  do {
+    PTRY(hipMalloc(&d_flag, BATCH_MAX * sizeof(int)));
+    PTRY(hipMalloc(&d_scan, BATCH_MAX * sizeof(int)));
+    PTRY(hipMalloc(&d_last, sizeof(int)));
+    PTRY(hipMalloc(&d_rpos, (size_t)BATCH_MAX * sizeof(float4)));
+    PTRY(hipMalloc(&d_rpow, (size_t)BATCH_MAX * sizeof(float4)));
+    PTRY(hipMalloc(&d_opos, (size_t)max_photons * sizeof(float4)));
+    PTRY(hipMalloc(&d_opow, (size_t)max_photons * sizeof(float4)));
+    PTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_scan, BATCH_MAX));
+    PTRY(hipMalloc(&d_tmp, tmp_bytes));
+    const float scale = (float)(1000.0 / (double)max_photons);  // scene.go:163-164
+    const float3 power0 = caustics ? make_float3(1.0f, 1.0f, 1.0f) : make_float3(15.0f, 15.0f, 15.0f);
+    int stored = 0;
+    unsigned long long emitted = 0;
+    bool failed = false;
+    // scene.go:146-161: lights in order; a light's loop also ends when the map is full
+    for (size_t li = 0; li < s->lights.size() && stored < max_photons && !failed; ++li) {
+      const grt_prim& lp = s->prims[s->lights[li]];
+      const grt_material& lm = s->mats[lp.material];
+      const double area = lm.color[0] + lm.color[1] + lm.color[2];
+      const long long target = std::min<long long>(max_photons, (long long)max_photons * (long long)(int)(s->light_area / area));
+      double pos[3];
+      for (int c = 0; c < 3; ++c) pos[c] = lp.kind == GRT_KIND_AABB ? (lp.b[c] + lp.a[c]) * 0.5 : lp.a[c];
+      const float4 lpos = make_float4((float)pos[0], (float)pos[1], (float)pos[2], 0.0f);
+      double yield = 0.0;
+      int empty_batches = 0;
+      while (stored < target) {
+        const int remaining = (int)(target - stored);
+        int batch = yield > 0.0 ? (int)std::min<double>(BATCH_MAX, remaining / yield * 1.05 + 4096) : std::min(BATCH_MAX, std::max(65536, 2 * remaining));
+        batch = std::max(batch, 1024);
+        const unsigned grid = (unsigned)((batch + 255) / 256);
+        hipLaunchKernelGGL(k_photon_trace, dim3(grid), dim3(256), 0, nullptr, ks, lpos, power0, caustics, emitted, batch, d_flag,
+                           d_rpos, d_rpow);
+        if (hipGetLastError() != hipSuccess) { failed = true; break; }
+        if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, batch) != hipSuccess) { failed = true; break; }
+        int minus1 = -1;
+        if (hipMemcpy(d_last, &minus1, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { failed = true; break; }
+        hipLaunchKernelGGL(k_photon_scatter, dim3(grid), dim3(256), 0, nullptr, d_flag, d_scan, batch, stored, (int)target, scale,
+                           d_rpos, d_rpow, d_opos, d_opow, d_last);
+        int last_scan = 0, last_flag = 0, last_emit = -1;
+        if (hipMemcpy(&last_scan, d_scan + batch - 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&last_flag, d_flag + batch - 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&last_emit, d_last, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { failed = true; break; }
+        const int got = last_scan + last_flag;
+        if (stored + got >= target) {
+          emitted += (unsigned long long)(last_emit >= 0 ? last_emit + 1 : batch);
+          stored = (int)target;
+        } else {
+          emitted += (unsigned long long)batch;
+          stored += got;
+        }
+        yield = std::max(1e-6, (double)got / batch);
+        // A scene that can never store (e.g. Lambert walls) would spin forever in
+        // the reference; give up after 64 fruitless batches.
+        empty_batches = got ? 0 : empty_batches + 1;
+        if (empty_batches >= 64) {
+          rc = grt_fail(GRT_EINVAL, "grt_photon_build: no photon stored in %llu emissions (no DiffuseMaterial surface reachable?)",
+                        emitted);
+          break;
+        }
+      }
+      if (rc) break;
+    }
+    if (rc) break;
+    if (failed) {
+      rc = grt_fail(GRT_EHIP, "grt_photon_build: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    pm->emitted = emitted;
+    std::vector<float4> hp(stored), hw(stored);
+    PTRY(hipMemcpy(hp.data(), d_opos, (size_t)stored * sizeof(float4), hipMemcpyDeviceToHost));
+    PTRY(hipMemcpy(hw.data(), d_opow, (size_t)stored * sizeof(float4), hipMemcpyDeviceToHost));
+    ph.resize(stored);
+    for (int i = 0; i < stored; ++i) {
+      ph[i].p[0] = hp[i].x, ph[i].p[1] = hp[i].y, ph[i].p[2] = hp[i].z;
+      memcpy(&ph[i].bits, &hp[i].w, 4);
+      ph[i].pw[0] = hw[i].x, ph[i].pw[1] = hw[i].y, ph[i].pw[2] = hw[i].z;
+      ph[i].src = i;
+    }
+    rc = upload_tree(ph, pm);
+  } while (0);
+  (void)hipFree(d_flag), (void)hipFree(d_scan), (void)hipFree(d_last), (void)hipFree(d_rpos), (void)hipFree(d_rpow);
+  (void)hipFree(d_opos), (void)hipFree(d_opow), (void)hipFree(d_tmp);
+  if (rc) {
+    grt_photon_free(pm);
+    return rc;
+  }
+  *out = pm;
+  return GRT_OK;
+}
+
+GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* power, const uint8_t* theta_phi, int32_t n,
+                            grt_pmap** out) {
+  if (!pos || !power || !theta_phi || n < 0 || !out) return grt_fail(GRT_EINVAL, "grt_photon_load: bad argument");
+  int dev;
+  int rc = pick_device(o, &dev);
+  if (rc) return rc;
+  std::vector<HostPhoton> ph(n);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) ph[i].p[k] = pos[3 * (size_t)i + k], ph[i].pw[k] = power[3 * (size_t)i + k];
+    ph[i].bits = ((int)theta_phi[2 * (size_t)i] << 8) | ((int)theta_phi[2 * (size_t)i + 1] << 16);
+    ph[i].src = i;
+  }
+  grt_pmap* pm = new grt_pmap;
+  pm->max = n;
+  pm->device = dev;
+  rc = upload_tree(ph, pm);
+  if (rc) {
+    grt_photon_free(pm);
+    return rc;
+  }
+  *out = pm;
+  return GRT_OK;
+}
+
+GRT_API int32_t grt_photon_count(const grt_pmap* pm) { return pm ? pm->n : 0; }
+GRT_API uint64_t grt_photon_emitted(const grt_pmap* pm) { return pm ? pm->emitted : 0; }
+
+GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_t* theta_phi) {
+  if (!pm) return grt_fail(GRT_EINVAL, "grt_photon_read: NULL map");
+  GRT_HIP(hipSetDevice(pm->device));
+  const size_t n = (size_t)pm->n;
+  std::vector<float4> p4(n + 1);
+  std::vector<float> w3(3 * (n + 1));
+  GRT_HIP(hipMemcpy(p4.data(), pm->d_pos4, p4.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  GRT_HIP(hipMemcpy(w3.data(), pm->d_pow3, w3.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 1; i <= n; ++i) {  // back to storage (emission) order
+    const size_t d = (size_t)pm->order[i];
+    int bits;
+    memcpy(&bits, &p4[i].w, 4);
+    if (pos) pos[3 * d] = p4[i].x, pos[3 * d + 1] = p4[i].y, pos[3 * d + 2] = p4[i].z;
+    if (power) power[3 * d] = w3[3 * i], power[3 * d + 1] = w3[3 * i + 1], power[3 * d + 2] = w3[3 * i + 2];
+    if (theta_phi) theta_phi[2 * d] = (uint8_t)(bits >> 8), theta_phi[2 * d + 1] = (uint8_t)(bits >> 16);
+  }
+  return GRT_OK;
+}
+
+GRT_API void grt_photon_free(grt_pmap* pm) {
+  if (!pm) return;
+  if (hipSetDevice(pm->device) == hipSuccess) {
+    (void)hipFree(pm->d_pos4);
+    (void)hipFree(pm->d_pow3);
+    (void)hipFree(pm->d_lut);
+  }
+  delete pm;
+}
+
+// ---- k-nearest gather -----------------------------------------------------------------------
+// The top TOP_NODES nodes of the tree (10 levels) are copied to LDS by every workgroup: every
+// query walks through them, deeper nodes are read from HBM / L2.
+#define TOP_NODES 1024
+#define GATHER_BLOCK 64
+
+struct TreeView {
+  const float4* __restrict__ pos4;
+  const float4* top;  // LDS copy of pos4[0 .. TOP_NODES)
+  int n;
+};
+GRT_DEV float4 node_at(const TreeView& T, int i) { return i < TOP_NODES ? T.top[i] : T.pos4[i]; }
+
+// Stackless walk of the implicit left-balanced tree in the order near subtree, node, far
+// subtree.  visit(i, node, d2) is called once per visited node; bound() returns the current
+// pruning radius^2.  State is (cur, last): the parent is cur >> 1, so no stack is needed.
+template <class Visit, class Bound>
+GRT_DEV void kd_walk(const TreeView& T, f3 q, Visit visit, Bound bound) {
+  int cur = 1, last = 0;
+  while (cur >= 1) {
+    const float4 nd = node_at(T, cur);
+    const int ax = __float_as_int(nd.w) & 3;
+    const float delta = (ax == 0 ? q.x - nd.x : (ax == 1 ? q.y - nd.y : q.z - nd.z));
+    const int nearc = 2 * cur + (delta < 0.0f ? 0 : 1), farc = 2 * cur + (delta < 0.0f ? 1 : 0);
+    bool do_visit = false;
+    if (last == (cur >> 1)) {        // arrived from the parent
+      if (nearc <= T.n) {
+        last = cur, cur = nearc;
+        continue;
+      }
+      do_visit = true;
+    } else if (last == nearc) {      // back from the near subtree
+      do_visit = true;
+    }
+    if (do_visit) {
+      const float dx = nd.x - q.x, dy = nd.y - q.y, dz = nd.z - q.z;
+      visit(cur, nd, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+      if (farc <= T.n && delta * delta <= bound()) {
+        last = cur, cur = farc;
+        continue;
+      }
+    }
+    last = cur, cur >>= 1;           // done with this subtree
+  }
+}
+
+// Pass 1: squared distance of the k-th nearest photon.  Max-heap of k floats per lane in LDS,
+// slot j of lane t at heap[j * GATHER_BLOCK + t] (conflict-free when lanes agree on j).
+__global__ __launch_bounds__(GATHER_BLOCK) void k_knn_radius(const float4* __restrict__ pos4, int n_photons,
+                                                             const float* __restrict__ qpos, int n_q, int k,
+                                                             float* __restrict__ rk2_out) {
+  extern __shared__ float4 smem4[];
+  float4* top = smem4;
+  float* heap = (float*)(smem4 + TOP_NODES);
+  for (int i = threadIdx.x; i < TOP_NODES; i += GATHER_BLOCK) top[i] = i <= n_photons ? pos4[i] : make_float4(0, 0, 0, 0);
+  __syncthreads();
+  const int qi = blockIdx.x * GATHER_BLOCK + threadIdx.x;
+  if (qi >= n_q) return;
+  TreeView T = {pos4, top, n_photons};
+  const f3 q = mk3(qpos[3 * (size_t)qi], qpos[3 * (size_t)qi + 1], qpos[3 * (size_t)qi + 2]);
+  float* h = heap + threadIdx.x;
+  int hn = 0;
+  float hmax = 3.402823466e38f;  // pruning bound: +inf until the heap is full
+  kd_walk(
+      T, q,
+      [&](int, const float4&, float d2) {
+        if (hn < k) {  // sift up
+          int i = hn++;
+          while (i > 0) {
+            int p = (i - 1) >> 1;
+            float pv = h[p * GATHER_BLOCK];
+            if (pv >= d2) break;
+            h[i * GATHER_BLOCK] = pv;
+            i = p;
+          }
+          h[i * GATHER_BLOCK] = d2;
+          if (hn == k) hmax = h[0];
+        } else if (d2 < hmax) {  // replace the root, sift down
+          int i = 0;
+          for (;;) {
+            int l = 2 * i + 1, r = l + 1, b = i;
+            float bv = d2;
+            if (l < k) {
+              float lv = h[l * GATHER_BLOCK];
+              if (lv > bv) b = l, bv = lv;
+            }
+            if (r < k) {
+              float rv = h[r * GATHER_BLOCK];
+              if (rv > bv) b = r, bv = rv;
+            }
+            if (b == i) break;
+            h[i * GATHER_BLOCK] = bv;
+            i = b;
+          }
+          h[i * GATHER_BLOCK] = d2;
+          hmax = h[0];
+        }
+      },
+      [&]() { return hmax; });
+  float rk2 = 0.0f;
+  if (hn == k) rk2 = h[0];
+  else
+    for (int i = 0; i < hn; ++i) rk2 = fmaxf(rk2, h[i * GATHER_BLOCK]);  // fewer than k photons: all of them
+  rk2_out[qi] = hn ? rk2 : -1.0f;
+}
+
+// Pass 2: IrradianceEst's loop over the k nearest (photon_mapping.go:138-161): every photon
+// with d2 <= rk2, radius filter, direction test against the LUT direction, power sum,
+// r2 = largest accepted d2, found < 8 -> unscaled sum.
+__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(const float4* __restrict__ pos4, const float* __restrict__ pow3,
+                                                         const float* __restrict__ lut, int n_photons,
+                                                         const float* __restrict__ qpos, const float* __restrict__ qnrm, int n_q,
+                                                         float radius, const float* __restrict__ rk2_in,
+                                                         float* __restrict__ irrad) {
+  extern __shared__ float4 smem4[];
+  float4* top = smem4;
+  for (int i = threadIdx.x; i < TOP_NODES; i += GATHER_BLOCK) top[i] = i <= n_photons ? pos4[i] : make_float4(0, 0, 0, 0);
+  __syncthreads();
+  const int qi = blockIdx.x * GATHER_BLOCK + threadIdx.x;
+  if (qi >= n_q) return;
+  TreeView T = {pos4, top, n_photons};
+  const f3 q = mk3(qpos[3 * (size_t)qi], qpos[3 * (size_t)qi + 1], qpos[3 * (size_t)qi + 2]);
+  const f3 nr = mk3(qnrm[3 * (size_t)qi], qnrm[3 * (size_t)qi + 1], qnrm[3 * (size_t)qi + 2]);
+  const float rk2 = rk2_in[qi];
+  const float radius2 = radius * radius;
+  f3 sum = mk3(0, 0, 0);
+  float r2 = 0.0f;
+  int found = 0;
+  if (rk2 >= 0.0f)
+    kd_walk(
+        T, q,
+        [&](int i, const float4& nd, float d2) {
+          if (d2 > rk2) return;
+          if (radius == 0.0f || d2 < radius2) {  // photon_mapping.go:141
+            const int bits = __float_as_int(nd.w);
+            const int th = (bits >> 8) & 255, ph = (bits >> 16) & 255;
+            const float st = lut[256 + th];
+            const float dx = st * lut[512 + ph], dy = st * lut[768 + ph], dz = lut[th];  // PhotonDir, :117-122
+            if (dx * nr.x + dy * nr.y + dz * nr.z < 0.0f) {                           // :144
+              sum.x += pow3[3 * (size_t)i], sum.y += pow3[3 * (size_t)i + 1], sum.z += pow3[3 * (size_t)i + 2];
+              r2 = fmaxf(r2, d2);
+              found++;
+            }
+          }
+        },
+        [&]() { return rk2; });
+  if (found >= 8) {  // :154-161
+    const float tmp = 1.0f / (PI_F * r2);
+    sum = sum * tmp;
+  }
+  irrad[3 * (size_t)qi] = sum.x, irrad[3 * (size_t)qi + 1] = sum.y, irrad[3 * (size_t)qi + 2] = sum.z;
+}
+
+#define GRT_GATHER_MAX_K 512
+
+GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (uint64_t)n * sizeof(float) : 0; }
+
+static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
+                         float* d_rk2, hipStream_t st) {
+  const unsigned grid = (unsigned)((n + GATHER_BLOCK - 1) / GATHER_BLOCK);
+  const size_t lds1 = TOP_NODES * sizeof(float4) + (size_t)k * GATHER_BLOCK * sizeof(float);
+  if (lds1 > 64 * 1024)
+    GRT_HIP(hipFuncSetAttribute((const void*)k_knn_radius, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+  hipLaunchKernelGGL(k_knn_radius, dim3(grid), dim3(GATHER_BLOCK), lds1, st, (const float4*)pm->d_pos4, pm->n, d_pos, n, k, d_rk2);
+  GRT_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), TOP_NODES * sizeof(float4), st, (const float4*)pm->d_pos4,
+                     (const float*)pm->d_pow3, (const float*)pm->d_lut, pm->n, d_pos, d_nrm, n, radius, (const float*)d_rk2, d_irrad);
+  GRT_HIP(hipGetLastError());
+  return GRT_OK;
+}
+
+static int gather_check(const grt_pmap* pm, const void* a, const void* b, const void* c, int n, int k) {
+  if (!pm || !a || !b || !c || n < 0) return grt_fail(GRT_EINVAL, "grt_photon_gather: bad argument");
+  if (k <= 0 || k > GRT_GATHER_MAX_K) return grt_fail(GRT_ELIMIT, "grt_photon_gather: k = %d outside 1..%d", k, GRT_GATHER_MAX_K);
+  return GRT_OK;
+}
+
+// d_workspace: grt_photon_gather_workspace_bytes(n) bytes of device memory (the per-query k-th
+// distance handed from pass 1 to pass 2).
+GRT_API int grt_photon_gather_dev(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int32_t n, float radius, int32_t k,
+                                  float* d_irrad, void* d_workspace, void* stream) {
+  int rc = gather_check(pm, d_pos, d_nrm, d_irrad, n, k);
+  if (rc) return rc;
+  if (!d_workspace) return grt_fail(GRT_EINVAL, "grt_photon_gather_dev: NULL workspace");
+  if (n == 0) return GRT_OK;
+  return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream);
+}
+
+GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float* nrm, int32_t n, float radius, int32_t k,
+                              float* irrad) {
+  int rc = gather_check(pm, pos, nrm, irrad, n, k);
+  if (rc) return rc;
+  if (n == 0) return GRT_OK;
+  GRT_HIP(hipSetDevice(pm->device));
+  float *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr, *d_rk2 = nullptr;
+  const size_t b3 = (size_t)n * 3 * sizeof(float);
+  rc = GRT_OK;
+  do {
+    PTRY(hipMalloc(&d_pos, b3));
+    PTRY(hipMalloc(&d_nrm, b3));
+    PTRY(hipMalloc(&d_out, b3));
+    PTRY(hipMalloc(&d_rk2, (size_t)n * sizeof(float)));
+    PTRY(hipMemcpy(d_pos, pos, b3, hipMemcpyHostToDevice));
+    PTRY(hipMemcpy(d_nrm, nrm, b3, hipMemcpyHostToDevice));
+    rc = gather_launch(pm, d_pos, d_nrm, n, radius, k, d_out, d_rk2, nullptr);
+    if (rc) break;
+    PTRY(hipMemcpy(irrad, d_out, b3, hipMemcpyDeviceToHost));
+  } while (0);
+  (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out), (void)hipFree(d_rk2);
+  return rc;
+}

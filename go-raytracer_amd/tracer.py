@@ -263,3 +263,64 @@ class Scene:
 
 def NewScene(width, height, cam, objects, globalPmap=None, causticPmap=None):  # scene.go:35
     return Scene(width, height, cam, objects, globalPmap, causticPmap)
+
+
+# ---- photon map (photon_mapping.go:84-209, scene.go:140-165) -------------------------
+class PhotonMap:
+    """tracer.PhotonMap: maxPhotons on the host, storage + kd-tree on the GPU (grt_pmap)."""
+
+    def __init__(self, maxPhotons=0, handle=None):
+        self.maxPhotons = int(maxPhotons)
+        self.handle = handle
+        self._lib = load()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.grt_photon_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def build(self, scene, caustics=False, seed=1):
+        """mapPhotons for this map (scene.go:152-160) + ScalePhotonPower(1000/max) (:163-164)."""
+        self.close()
+        h = C.c_void_p()
+        o = Scene.opts(seed)
+        check(self._lib.grt_photon_build(scene.handle, C.byref(o), self.maxPhotons, int(caustics), C.byref(h)))
+        self.handle = h
+        return self
+
+    @classmethod
+    def load(cls, pos, power, theta_phi):
+        pos = np.ascontiguousarray(pos, np.float32)
+        power = np.ascontiguousarray(power, np.float32)
+        tp = np.ascontiguousarray(theta_phi, np.uint8)
+        h = C.c_void_p()
+        o = Scene.opts(1)
+        check(load().grt_photon_load(C.byref(o), _ptr(pos), _ptr(power), _ptr(tp), pos.shape[0], C.byref(h)))
+        return cls(pos.shape[0], h)
+
+    def count(self):
+        return int(self._lib.grt_photon_count(self.handle))
+
+    def emitted(self):
+        return int(self._lib.grt_photon_emitted(self.handle))
+
+    def read(self):
+        n = self.count()
+        pos, power, tp = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty((n, 2), np.uint8)
+        check(self._lib.grt_photon_read(self.handle, _ptr(pos), _ptr(power), _ptr(tp)))
+        return pos, power, tp
+
+    def IrradianceEst(self, pos, normal, radius, nphotons):
+        """photon_mapping.go:125 for a batch: pos, normal [n, 3] -> irradiance [n, 3]."""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        out = np.empty_like(pos)
+        check(self._lib.grt_photon_gather(self.handle, _ptr(pos), _ptr(nrm), pos.shape[0], float(radius),
+                                          int(nphotons), _ptr(out)))
+        return out
+
+
+def NewPhotonMap(maxPhotons):  # photon_mapping.go:97
+    return PhotonMap(maxPhotons)

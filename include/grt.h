@@ -181,21 +181,29 @@ int grt_primary_sweep_dev(grt_scene* scene, const grt_opts* opts, int32_t sample
 int grt_photon_build(grt_scene* scene, const grt_opts* opts, int32_t max_photons, int32_t caustics,
                      grt_pmap** out);
 int32_t grt_photon_count(const grt_pmap* pmap);
-/* Copies the stored photons (kd-tree order) to host arrays: pos[n*3], power[n*3] float32,
- * theta_phi[n*2] bytes (photon_mapping.go:11-16).  Any pointer may be NULL. */
+/* Photons emitted to fill the map (the reference's loop count, scene.go:152/157). */
+uint64_t grt_photon_emitted(const grt_pmap* pmap);
+/* Copies the stored photons, in storage (= emission) order, to host arrays: pos[n*3],
+ * power[n*3] float32 (already scaled), theta_phi[n*2] bytes (photon_mapping.go:11-16).
+ * Any pointer may be NULL. */
 int grt_photon_read(const grt_pmap* pmap, float* pos, float* power, uint8_t* theta_phi);
 /* Builds a map from caller-supplied photons instead of emitting (for gather parity). */
 int grt_photon_load(const grt_opts* opts, const float* pos, const float* power,
                     const uint8_t* theta_phi, int32_t n, grt_pmap** out);
 /* IrradianceEst batch (photon_mapping.go:125-162): for each of n queries, the k nearest
- * photons; radius==0 => use all k; sums power of photons with dir.normal < 0, divides by
+ * photons (all photons tied at the k-th distance are kept); radius==0 => use all of them,
+ * else those with d^2 < radius^2; sums power of photons with dir.normal < 0, divides by
  * pi*r2 when at least 8 were found (else returns the unscaled sum).  r2 = the largest
  * accepted squared distance (documented intent, photon_mapping.go:136).
- * Host buffers: pos_xyz[n*3], nrm_xyz[n*3], irrad_rgb[n*3]. */
+ * k <= 512.  Host buffers: pos_xyz[n*3], nrm_xyz[n*3], irrad_rgb[n*3]. */
 int grt_photon_gather(const grt_pmap* pmap, const float* pos_xyz, const float* nrm_xyz, int32_t n,
                       float radius, int32_t k, float* irrad_rgb);
+/* Device-pointer variant: enqueues on `stream`, allocates nothing; d_workspace holds
+ * grt_photon_gather_workspace_bytes(n) bytes (per-query k-th distance between the passes). */
 int grt_photon_gather_dev(const grt_pmap* pmap, const float* d_pos_xyz, const float* d_nrm_xyz,
-                          int32_t n, float radius, int32_t k, float* d_irrad_rgb, void* stream);
+                          int32_t n, float radius, int32_t k, float* d_irrad_rgb,
+                          void* d_workspace, void* stream);
+uint64_t grt_photon_gather_workspace_bytes(int32_t n);
 void grt_photon_free(grt_pmap* pmap);
 
 /* ---- misc ----------------------------------------------------------------------------- */

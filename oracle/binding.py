@@ -39,6 +39,15 @@ PROTOTYPES = {
     "grto_render_accum": (C.c_int, [_vp, C.c_uint64, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "grto_primary_hits": (C.c_int, [_vp, C.c_uint64, C.c_int32, _vp, _vp, _vp]),
     "grto_last_ray_count": (C.c_uint64, []),
+    "grto_photon_quantize": (None, [_d3, _vp]),
+    "grto_photon_dir": (None, [C.c_uint8, C.c_uint8, _d3]),
+    "grto_photon_build": (C.c_int, [_vp, C.c_uint64, C.c_int32, C.c_int32, P(_vp), C.c_uint64]),
+    "grto_photon_count": (C.c_int32, [_vp]),
+    "grto_photon_emitted": (C.c_uint64, [_vp]),
+    "grto_photon_read": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "grto_photon_load": (C.c_int, [_vp, _vp, _vp, C.c_int32, P(_vp)]),
+    "grto_photon_gather": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_double, C.c_int32, _vp, C.c_int32, C.c_int32]),
+    "grto_photon_free": (None, [_vp]),
     "grto_version": (C.c_char_p, []),
 }
 
@@ -124,3 +133,54 @@ class OracleScene:
 
     def last_ray_count(self):
         return int(self.lib.grto_last_ray_count())
+
+
+class OraclePhotonMap:
+    """PhotonMap (photon_mapping.go:84-209) in float64: emission order storage + exact kNN."""
+
+    def __init__(self, handle):
+        self.lib = load()
+        self.handle = handle
+
+    @classmethod
+    def build(cls, oscene, max_photons, caustics=False, seed=1, max_emit=1 << 40):
+        h = _vp()
+        rc = load().grto_photon_build(oscene.handle, seed, max_photons, int(caustics), C.byref(h), max_emit)
+        assert rc == 0, rc
+        return cls(h)
+
+    @classmethod
+    def load(cls, pos, power, theta_phi):
+        pos = np.ascontiguousarray(pos, np.float64)
+        power = np.ascontiguousarray(power, np.float64)
+        tp = np.ascontiguousarray(theta_phi, np.uint8)
+        h = _vp()
+        rc = load().grto_photon_load(_ptr(pos), _ptr(power), _ptr(tp), pos.shape[0], C.byref(h))
+        assert rc == 0, rc
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.grto_photon_free(self.handle)
+            self.handle = None
+
+    def count(self):
+        return int(self.lib.grto_photon_count(self.handle))
+
+    def emitted(self):
+        return int(self.lib.grto_photon_emitted(self.handle))
+
+    def read(self):
+        n = self.count()
+        pos, power, tp = np.empty((n, 3)), np.empty((n, 3)), np.empty((n, 2), np.uint8)
+        assert self.lib.grto_photon_read(self.handle, _ptr(pos), _ptr(power), _ptr(tp)) == 0
+        return pos, power, tp
+
+    def gather(self, pos, nrm, radius, k, brute=False, nthreads=0):
+        pos = np.ascontiguousarray(pos, np.float64)
+        nrm = np.ascontiguousarray(nrm, np.float64)
+        out = np.empty_like(pos)
+        rc = self.lib.grto_photon_gather(self.handle, _ptr(pos), _ptr(nrm), pos.shape[0], radius, k, _ptr(out),
+                                         int(brute), nthreads)
+        assert rc == 0, rc
+        return out

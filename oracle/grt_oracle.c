@@ -581,4 +581,6 @@ GRTO_API int grto_primary_hits(const grto_scene* s, uint64_t seed, int32_t jitte
   return GRT_OK;
 }
 
+#include "grt_oracle_photon.h"
+
 GRTO_API const char* grto_version(void) { return "grt-oracle 0.1 (float64 C restatement; test infrastructure)"; }

@@ -1,0 +1,375 @@
+/*
+ * grt_oracle_photon.h — TEST INFRASTRUCTURE (included at the end of grt_oracle.c).
+ *
+ * Float64 restatement of the reference's photon pass:
+ *   mapPhotons / tracePhotons            pkg/tracer/scene.go:140-165, 354-424
+ *   Photon, PhotonMap, Store, PhotonDir,
+ *   ScalePhotonPower, IrradianceEst       pkg/tracer/photon_mapping.go:11-16, 84-209
+ *
+ * PARITY UNPINNED.  The reference never runs this code (the call is commented out at
+ * scene.go:83, the gather at scene.go:308-320), ships no output of it, and delegates storage
+ * and the k-nearest search to gonum.org/v1/gonum v0.9.3 spatial/kdtree (go.mod:8), whose source
+ * is not under /root/reference.  What is restated is the published algorithm at the reference's
+ * call sites: Insert = append (photon_mapping.go:192), New(list, true) = any balanced tree
+ * (:207), NearestSet + NKeeper(k) = the k photons of smallest squared distance (:131-133,
+ * distance = dist2, :37-51).  Decisions where the source leaves room:
+ *   - ties at the k-th distance: ALL photons at that distance are kept (gonum's choice depends
+ *     on its traversal order, which cannot be checked offline; this rule is order-free);
+ *   - r2 = the largest accepted squared distance (the documented intent, photon_mapping.go:136;
+ *     the code takes the last accepted entry in gonum's heap-array order);
+ *   - found < 8 returns the unscaled sum, exactly as written (:154-156);
+ *   - several lights: the reference's loops cannot terminate once the map is full
+ *     (scene.go:152 with Store's cap at :166); here a light's loop also ends when the map is full.
+ * The RNG is the counter generator: pixel = emission index, sample = map id (0 global,
+ * 1 caustic), dimensions GRT_PDIM_* as in go-raytracer_amd/csrc/grt_rng.h.
+ */
+
+#define PDIM_EMIT_U 0u
+#define PDIM_EMIT_V 1u
+#define PDIM_HIT(depth, k) (2u + 4u * (uint32_t)((depth)-1) + (uint32_t)(k))
+
+typedef struct { /* photon_mapping.go:11-16 (plane is the kd-tree's, kept with the tree) */
+  double pos[3];
+  double power[3];
+  uint8_t theta, phi;
+} ophoton;
+
+typedef struct {
+  int photon; /* index into ph[] */
+  int axis;   /* split axis, -1 = leaf */
+  int left, right;
+} okdnode;
+
+struct grto_pmap {
+  ophoton* ph;
+  int n, max;
+  uint64_t emitted;
+  double costheta[256], sintheta[256], cosphi[256], sinphi[256]; /* photon_mapping.go:90-93 */
+  okdnode* nodes; /* balanced kd-tree over ph[] (kdtree.New(list, true), photon_mapping.go:207) */
+  int n_nodes, root;
+};
+typedef struct grto_pmap grto_pmap;
+
+static grto_pmap* pmap_new(int max) { /* NewPhotonMap, photon_mapping.go:97-114 */
+  grto_pmap* m = (grto_pmap*)calloc(1, sizeof *m);
+  m->max = max;
+  m->ph = (ophoton*)malloc(sizeof(ophoton) * (size_t)(max > 0 ? max : 1));
+  for (int i = 0; i < 256; i++) {
+    double angle = (double)i * (1.0 / 256.0) * M_PI;
+    m->costheta[i] = cos(angle);
+    m->sintheta[i] = sin(angle);
+    m->cosphi[i] = cos(2.0 * angle);
+    m->sinphi[i] = sin(2.0 * angle);
+  }
+  m->root = -1;
+  return m;
+}
+
+/* Direction quantisation of Store (photon_mapping.go:177-191); Go's int() truncates. */
+GRTO_API void grto_photon_quantize(const double* dir, uint8_t* theta_phi) {
+  int theta = (int)(acos(dir[2]) * (256.0 / M_PI));
+  theta_phi[0] = theta > 255 ? 255 : (uint8_t)theta;
+  int phi = (int)(atan2(dir[1], dir[0]) * (256.0 / (2.0 * M_PI)));
+  if (phi > 255) theta_phi[1] = 255;
+  else if (phi < 0) theta_phi[1] = (uint8_t)(phi + 256);
+  else theta_phi[1] = (uint8_t)phi;
+}
+/* PhotonDir (photon_mapping.go:117-122). */
+GRTO_API void grto_photon_dir(uint8_t theta, uint8_t phi, double* dir) {
+  static grto_pmap* lut;
+  if (!lut) lut = pmap_new(0);
+  dir[0] = lut->sintheta[theta] * lut->cosphi[phi];
+  dir[1] = lut->sintheta[theta] * lut->sinphi[phi];
+  dir[2] = lut->costheta[theta];
+}
+
+static void pmap_store(grto_pmap* m, v3 power, v3 pos, v3 dir) { /* photon_mapping.go:165-193 */
+  if (m->n >= m->max) return;
+  ophoton* p = &m->ph[m->n++];
+  to3(p->pos, pos);
+  to3(p->power, power);
+  double d[3];
+  to3(d, dir);
+  uint8_t tp[2];
+  grto_photon_quantize(d, tp);
+  p->theta = tp[0];
+  p->phi = tp[1];
+}
+
+/* tracePhotons (scene.go:354-424), iterative: every branch makes at most one recursive call. */
+static void trace_photon(const grto_scene* s, ray r, v3 power, grto_pmap* m, int caustics, uint32_t key) {
+  for (int depth = 1; depth < s->d.max_depth; depth++) { /* :355 */
+    double tNear;
+    if (caustics && depth == 1) { /* :359-363 */
+      double tt;
+      if (intersect(s, r, s->tobjects, s->n_tobjects, &tt) < 0) return;
+    }
+    int id = intersect(s, r, NULL, s->n_prims, &tNear); /* :365 */
+    if (id < 0) return;
+    v3 incident = v_unit(r.dir); /* :371 */
+    v3 p = ray_at(r, tNear);
+    const grt_prim* o = &s->prims[id];
+    v3 n = prim_surface(o, p);
+    const grt_material* mt = &s->mats[o->material];
+    if (caustics && depth == 1 && !mt->transparent) return; /* :375 */
+    v3 orientedN = n;                                        /* :380-383 */
+    if (v_dot(n, incident) >= 0.0) orientedN = v_inv(orientedN);
+    v3 f = from3(mt->color);
+    double rrp = (f.x + f.y + f.z) / 3;           /* :388 */
+    if (mt->normal || mt->emittance > 0) return;  /* :391-393 */
+    if (mt->lambert) {                            /* :395-396: nothing happens, the photon is lost */
+      return;
+    } else if (mt->reflectivity > 0) { /* :397-402 */
+      v3 refl = reflect(incident, n);
+      v3 fz = sample_hemisphere_normal(orientedN, rng_draw(key, PDIM_HIT(depth, 0)), rng_draw(key, PDIM_HIT(depth, 1)));
+      refl = v_plus(refl, v_scale(fz, mt->roughness));
+      r.orig = p;
+      r.dir = refl;
+      power = v_times(f, power);
+    } else if (mt->transparent) { /* :403-412 */
+      v3 dir;
+      if (!refract(incident, n, 1.0 / mt->refr_index, rng_draw(key, PDIM_HIT(depth, 2)), &dir)) dir = reflect(incident, n);
+      r.orig = p;
+      r.dir = dir;
+    } else {
+      if (rng_draw(key, PDIM_HIT(depth, 3)) < rrp) { /* :414-417 absorb */
+        pmap_store(m, v_scale(v_times(f, power), 1.0 / (1.0 - rrp)), p, incident);
+        return;
+      }
+      r.orig = p; /* :418-422 */
+      r.dir = sample_hemisphere_normal(n, rng_draw(key, PDIM_HIT(depth, 0)), rng_draw(key, PDIM_HIT(depth, 1)));
+      power = v_scale(v_times(f, power), 1.0 / rrp);
+    }
+  }
+}
+
+/* ---- balanced kd-tree + exact k-nearest (stands for gonum kdtree.New / NearestSet) ---- */
+static int kd_axis_cmp_axis;
+static const ophoton* kd_cmp_ph;
+static int kd_cmp(const void* a, const void* b) {
+  double x = kd_cmp_ph[*(const int*)a].pos[kd_axis_cmp_axis], y = kd_cmp_ph[*(const int*)b].pos[kd_axis_cmp_axis];
+  return (x > y) - (x < y);
+}
+static int kd_build(grto_pmap* m, int* idx, int n, int depth) {
+  if (n <= 0) return -1;
+  int axis = depth % 3; /* gonum cycles the dimensions */
+  kd_axis_cmp_axis = axis;
+  kd_cmp_ph = m->ph;
+  qsort(idx, (size_t)n, sizeof(int), kd_cmp);
+  int mid = n / 2;
+  int me = m->n_nodes++;
+  m->nodes[me].photon = idx[mid];
+  m->nodes[me].axis = axis;
+  int l = kd_build(m, idx, mid, depth + 1);
+  int r = kd_build(m, idx + mid + 1, n - mid - 1, depth + 1);
+  m->nodes[me].left = l;
+  m->nodes[me].right = r;
+  return me;
+}
+static void pmap_build_tree(grto_pmap* m) {
+  free(m->nodes);
+  m->nodes = (okdnode*)malloc(sizeof(okdnode) * (size_t)(m->n > 0 ? m->n : 1));
+  m->n_nodes = 0;
+  int* idx = (int*)malloc(sizeof(int) * (size_t)(m->n > 0 ? m->n : 1));
+  for (int i = 0; i < m->n; i++) idx[i] = i;
+  m->root = kd_build(m, idx, m->n, 0);
+  free(idx);
+}
+
+typedef struct {
+  double* d2; /* max-heap of the k smallest squared distances seen */
+  int n, k;
+} kheap;
+static void kheap_push(kheap* h, double d) {
+  if (h->n < h->k) {
+    int i = h->n++;
+    h->d2[i] = d;
+    while (i > 0 && h->d2[(i - 1) / 2] < h->d2[i]) {
+      double t = h->d2[i];
+      h->d2[i] = h->d2[(i - 1) / 2];
+      h->d2[(i - 1) / 2] = t;
+      i = (i - 1) / 2;
+    }
+  } else if (d < h->d2[0]) {
+    int i = 0;
+    h->d2[0] = d;
+    for (;;) {
+      int l = 2 * i + 1, r = l + 1, b = i;
+      if (l < h->n && h->d2[l] > h->d2[b]) b = l;
+      if (r < h->n && h->d2[r] > h->d2[b]) b = r;
+      if (b == i) break;
+      double t = h->d2[i];
+      h->d2[i] = h->d2[b];
+      h->d2[b] = t;
+      i = b;
+    }
+  }
+}
+static double pdist2(const ophoton* p, const double* q) { /* dist2, photon_mapping.go:37-51 */
+  double d1 = p->pos[0] - q[0];
+  double d2 = d1 * d1;
+  d1 = p->pos[1] - q[1];
+  d2 += d1 * d1;
+  d1 = p->pos[2] - q[2];
+  d2 += d1 * d1;
+  return d2;
+}
+static void kd_knn(const grto_pmap* m, int node, const double* q, kheap* h) {
+  if (node < 0) return;
+  const okdnode* nd = &m->nodes[node];
+  const ophoton* p = &m->ph[nd->photon];
+  double delta = q[nd->axis] - p->pos[nd->axis];
+  int nearc = delta < 0 ? nd->left : nd->right, farc = delta < 0 ? nd->right : nd->left;
+  kd_knn(m, nearc, q, h);
+  kheap_push(h, pdist2(p, q));
+  if (h->n < h->k || delta * delta <= h->d2[0]) kd_knn(m, farc, q, h);
+}
+
+typedef struct {
+  double irrad[3], r2;
+  int found;
+} gather_acc;
+static void gather_one(const grto_pmap* m, const ophoton* p, double d2, double rk2, const double* nrm, double radius,
+                       gather_acc* a) {
+  if (d2 > rk2) return;                        /* not among the k nearest */
+  if (radius == 0.0 || d2 < radius * radius) { /* photon_mapping.go:141 */
+    double dx = m->sintheta[p->theta] * m->cosphi[p->phi], dy = m->sintheta[p->theta] * m->sinphi[p->phi];
+    double dz = m->costheta[p->theta];
+    if (dx * nrm[0] + dy * nrm[1] + dz * nrm[2] < 0.0) { /* :144 */
+      a->irrad[0] += p->power[0];
+      a->irrad[1] += p->power[1];
+      a->irrad[2] += p->power[2];
+      if (d2 > a->r2) a->r2 = d2;
+      a->found++;
+    }
+  }
+}
+static void kd_range(const grto_pmap* m, int node, const double* q, double rk2, const double* nrm, double radius,
+                     gather_acc* a) {
+  if (node < 0) return;
+  const okdnode* nd = &m->nodes[node];
+  const ophoton* p = &m->ph[nd->photon];
+  double delta = q[nd->axis] - p->pos[nd->axis];
+  if (delta < 0 || delta * delta <= rk2) kd_range(m, nd->left, q, rk2, nrm, radius, a);
+  gather_one(m, p, pdist2(p, q), rk2, nrm, radius, a);
+  if (delta >= 0 || delta * delta <= rk2) kd_range(m, nd->right, q, rk2, nrm, radius, a);
+}
+
+/* IrradianceEst (photon_mapping.go:125-162).  brute != 0 scans every photon instead of using
+ * the tree (cross-check of the tree, small maps only).  Photons are visited in index order
+ * (tree: in-order by position), sums are order-dependent only in the last float64 bits. */
+static void irradiance_est(const grto_pmap* m, const double* pos, const double* nrm, double radius, int k, int brute,
+                           double* out) {
+  out[0] = out[1] = out[2] = 0.0;
+  if (m->n == 0 || k <= 0) return;
+  kheap h = {(double*)malloc(sizeof(double) * (size_t)k), 0, k};
+  if (brute)
+    for (int i = 0; i < m->n; i++) kheap_push(&h, pdist2(&m->ph[i], pos));
+  else
+    kd_knn(m, m->root, pos, &h);
+  double rk2 = h.d2[0]; /* k-th smallest squared distance (or the largest when n < k) */
+  free(h.d2);
+  gather_acc a = {{0, 0, 0}, 0.0, 0};
+  if (brute)
+    for (int i = 0; i < m->n; i++) gather_one(m, &m->ph[i], pdist2(&m->ph[i], pos), rk2, nrm, radius, &a);
+  else
+    kd_range(m, m->root, pos, rk2, nrm, radius, &a);
+  out[0] = a.irrad[0], out[1] = a.irrad[1], out[2] = a.irrad[2];
+  if (a.found < 8) return; /* :154-156 */
+  double tmp = 1.0 / (M_PI * a.r2); /* :159 */
+  out[0] *= tmp, out[1] *= tmp, out[2] *= tmp;
+}
+
+/* mapPhotons for one map (scene.go:140-165) + ScalePhotonPower(1000/max) (photon_mapping.go:197-209). */
+GRTO_API int grto_photon_build(const grto_scene* s, uint64_t seed, int32_t max_photons, int32_t caustics,
+                               grto_pmap** out, uint64_t max_emit) {
+  if (!s || !out || max_photons <= 0) return GRT_EINVAL;
+  grto_pmap* m = pmap_new(max_photons);
+  uint32_t seed32 = rng_seed32(seed);
+  uint64_t e = 0;
+  v3 power0 = caustics ? V(1.0, 1.0, 1.0) : V(15.0, 15.0, 15.0); /* scene.go:154,159 */
+  for (int li = 0; li < s->n_lights && m->n < m->max; li++) {
+    const grt_prim* l = &s->prims[s->lights[li]];
+    const double* c = s->mats[l->material].color;
+    double area = c[0] + c[1] + c[2];
+    v3 pos = prim_pos(l), nl = V(0, -1, 0); /* scene.go:149-150 */
+    long target = (long)m->max * (long)(int)(s->light_area / area);
+    while (m->n < target && m->n < m->max && e < max_emit) { /* scene.go:152 / :157 */
+      uint32_t key = rng_path_key(rng_pixel_key(seed32, (uint32_t)e), (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
+      ray rp = {pos, sample_hemisphere_normal(nl, rng_draw(key, PDIM_EMIT_U), rng_draw(key, PDIM_EMIT_V))};
+      trace_photon(s, rp, power0, m, caustics, key);
+      e++;
+    }
+  }
+  m->emitted = e;
+  double scale = 1000.0 / (double)m->max; /* scene.go:163-164 */
+  for (int i = 0; i < m->n; i++)
+    for (int k = 0; k < 3; k++) m->ph[i].power[k] *= scale;
+  pmap_build_tree(m);
+  *out = m;
+  return GRT_OK;
+}
+GRTO_API int32_t grto_photon_count(const grto_pmap* m) { return m ? m->n : 0; }
+GRTO_API uint64_t grto_photon_emitted(const grto_pmap* m) { return m ? m->emitted : 0; }
+/* Photons in storage (= emission) order. */
+GRTO_API int grto_photon_read(const grto_pmap* m, double* pos, double* power, uint8_t* theta_phi) {
+  if (!m) return GRT_EINVAL;
+  for (int i = 0; i < m->n; i++) {
+    if (pos) memcpy(pos + 3 * (size_t)i, m->ph[i].pos, 24);
+    if (power) memcpy(power + 3 * (size_t)i, m->ph[i].power, 24);
+    if (theta_phi) theta_phi[2 * (size_t)i] = m->ph[i].theta, theta_phi[2 * (size_t)i + 1] = m->ph[i].phi;
+  }
+  return GRT_OK;
+}
+GRTO_API int grto_photon_load(const double* pos, const double* power, const uint8_t* theta_phi, int32_t n,
+                              grto_pmap** out) {
+  if (!pos || !power || !theta_phi || n < 0 || !out) return GRT_EINVAL;
+  grto_pmap* m = pmap_new(n);
+  m->n = n;
+  for (int i = 0; i < n; i++) {
+    memcpy(m->ph[i].pos, pos + 3 * (size_t)i, 24);
+    memcpy(m->ph[i].power, power + 3 * (size_t)i, 24);
+    m->ph[i].theta = theta_phi[2 * (size_t)i];
+    m->ph[i].phi = theta_phi[2 * (size_t)i + 1];
+  }
+  pmap_build_tree(m);
+  *out = m;
+  return GRT_OK;
+}
+
+typedef struct {
+  const grto_pmap* m;
+  const double *pos, *nrm;
+  double* out;
+  double radius;
+  int k, brute, n;
+  volatile int* next;
+} gjob;
+static void* gather_worker(void* arg) {
+  gjob* j = (gjob*)arg;
+  for (;;) {
+    int i0 = __sync_fetch_and_add(j->next, 256);
+    if (i0 >= j->n) break;
+    for (int i = i0; i < i0 + 256 && i < j->n; i++)
+      irradiance_est(j->m, j->pos + 3 * (size_t)i, j->nrm + 3 * (size_t)i, j->radius, j->k, j->brute, j->out + 3 * (size_t)i);
+  }
+  return NULL;
+}
+GRTO_API int grto_photon_gather(const grto_pmap* m, const double* pos, const double* nrm, int32_t n, double radius,
+                                int32_t k, double* irrad, int32_t brute, int32_t nthreads) {
+  if (!m || !pos || !nrm || !irrad || n < 0) return GRT_EINVAL;
+  if (nthreads <= 0) nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+  if (nthreads > 256) nthreads = 256;
+  volatile int next = 0;
+  gjob j = {m, pos, nrm, irrad, radius, k, brute, n, &next};
+  pthread_t th[256];
+  for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, gather_worker, &j);
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  return GRT_OK;
+}
+GRTO_API void grto_photon_free(grto_pmap* m) {
+  if (!m) return;
+  free(m->ph);
+  free(m->nodes);
+  free(m);
+}

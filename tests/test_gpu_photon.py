@@ -1,0 +1,119 @@
+"""Config C4 parity: photon emission and k-nearest radiance gather, HIP through the C ABI
+against the float64 restatement.  PARITY UNPINNED against the reference itself (see
+oracle/grt_oracle_photon.h): what is checked is HIP == oracle on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_matches_oracle_on_loaded_photons(pkg, ob):
+    """Same photons on both sides (float32-exact positions), queries on and off the surfaces."""
+    rs = np.random.RandomState(11)
+    n = 50000
+    pos = rs.uniform(0, 555, (n, 3)).astype(np.float32)
+    pos[: n // 2, 1] = 0.1                                    # a dense floor sheet
+    pw = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+    tp = rs.randint(0, 256, (n, 2)).astype(np.uint8)
+    g = pkg.tracer.PhotonMap.load(pos, pw, tp)
+    o = ob.OraclePhotonMap.load(pos.astype(np.float64), pw.astype(np.float64), tp)
+    assert g.count() == n
+    rpos, rpw, rtp = g.read()
+    assert (rpos == pos).all() and (rpw == pw).all() and (rtp == tp).all()   # storage order survives the tree
+    q = rs.uniform(0, 555, (4000, 3)).astype(np.float32)
+    q[:2000, 1] = 0.1
+    nr = rs.normal(size=(4000, 3)).astype(np.float32)
+    for radius, k in ((0.0, 100), (0.0, 50), (30.0, 100), (1.0, 100), (0.0, 1), (0.0, 7)):
+        a = g.IrradianceEst(q, nr, radius, k).astype(np.float64)
+        b = o.gather(q.astype(np.float64), nr.astype(np.float64), radius, k)
+        close = np.isclose(a, b, rtol=2e-4, atol=1e-9).all(1)
+        # FP32 squared distances can order two photons at the k-th place differently from float64:
+        # such a query differs by one photon's power (~1/k of the sum)
+        assert close.mean() > 0.99, (radius, k, close.mean())
+        scale = np.abs(b).max(1) + 1e-12
+        assert (np.abs(a - b).max(1) / scale)[~close].max(initial=0) < 0.5
+
+
+def test_gather_edge_cases(pkg, ob):
+    # ties: a regular grid; every photon at the k-th distance is kept on both sides
+    xs, zs = np.meshgrid(np.arange(12, dtype=np.float32), np.arange(12, dtype=np.float32))
+    pos = np.stack([xs.ravel(), np.zeros(144, np.float32), zs.ravel()], 1)
+    pw = np.tile(np.array([0.5, 0.25, 0.125], np.float32), (144, 1))
+    tp = np.tile(np.array([255, 0], np.uint8), (144, 1))
+    g = pkg.tracer.PhotonMap.load(pos, pw, tp)
+    o = ob.OraclePhotonMap.load(pos.astype(np.float64), pw.astype(np.float64), tp)
+    q = np.array([[5, 0, 5], [0, 0, 0], [5.5, 0, 5.5], [100, 3, -7]], np.float32)
+    up = np.tile(np.array([0, 0, 1], np.float32), (4, 1))
+    for radius, k in ((0.0, 9), (0.0, 5), (0.0, 2), (1.5, 25), (0.0, 500), (0.0, 144)):
+        np.testing.assert_allclose(g.IrradianceEst(q, up, radius, k), o.gather(q.astype(np.float64), up.astype(np.float64), radius, k),
+                                   rtol=1e-5)
+    assert (g.IrradianceEst(q, -up, 0.0, 9) == 0).all()
+    # one photon, and an empty query batch
+    g1 = pkg.tracer.PhotonMap.load(pos[:1], pw[:1], tp[:1])
+    np.testing.assert_allclose(g1.IrradianceEst(q[:1], up[:1], 0.0, 100), [[0.5, 0.25, 0.125]])
+    assert g1.IrradianceEst(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.0, 10).shape == (0, 3)
+    with pytest.raises(pkg._capi.GrtError):
+        g1.IrradianceEst(q, up, 0.0, 100000)       # k beyond the documented maximum
+
+
+@pytest.mark.parametrize("caustics,n", [(False, 20000), (True, 3000)])
+def test_emission_matches_oracle(pkg, ob, caustics, n):
+    """One thread per emitted photon keyed by emission index reproduces the sequential loop of
+    scene.go:152-160: same stored count, nearly the same emission count, and photon i is the same
+    photon (FP32 vs float64 walks part ways only at intersection ties / roulette thresholds)."""
+    scene = pkg.scenes.cornell(64, 64, "cornell8d")
+    g = pkg.tracer.PhotonMap(n).build(scene, caustics=caustics, seed=3)
+    o = ob.OraclePhotonMap.build(ob.OracleScene(scene.flat), n, caustics, seed=3)
+    assert g.count() == o.count() == n
+    assert abs(g.emitted() - o.emitted()) <= max(4, 2e-3 * o.emitted()), (g.emitted(), o.emitted())
+    gp, gw, gt = g.read()
+    op, ow, ot = o.read()
+    # One divergent walk (stored on one side, bounced on the other) shifts every later index by
+    # one, so photons are matched by position, not by index.
+    from scipy.spatial import cKDTree
+
+    dist, j = cKDTree(op).query(gp, k=1)
+    same = dist < 2e-2
+    shift = np.abs(j[same] - np.nonzero(same)[0])
+    print(f"caustics={caustics}: emitted {g.emitted()} vs {o.emitted()}, photons with a twin {same.mean():.5f}, "
+          f"max index shift {shift.max()}")
+    assert same.mean() > 0.995 and shift.max() <= 8
+    assert np.isclose(gw[same], ow[j[same]], rtol=1e-4).all()
+    dt = np.abs(gt[same].astype(int) - ot[j[same]].astype(int))
+    dt[:, 1] = np.minimum(dt[:, 1], 256 - dt[:, 1])
+    assert (dt <= 1).all() and (dt == 0).mean() > 0.99     # direction bytes: FP32 acos/atan2 at a bin edge
+
+
+def test_lambert_scene_reports_instead_of_spinning(pkg):
+    """With Lambert walls tracePhotons never stores (scene.go:395-396) and the reference's loop
+    (scene.go:152) never ends; the library gives up with an error."""
+    scene = pkg.scenes.cornell(32, 32, "cornell8")
+    with pytest.raises(pkg._capi.GrtError, match="no photon stored"):
+        pkg.tracer.PhotonMap(1000).build(scene, caustics=False, seed=1)
+
+
+def test_c4_radiance_gather_on_primary_hits(pkg, ob):
+    """The C4 pipeline at test size: global map on cornell8d, one query per primary hit with its
+    surface normal, k = 100, radius 0 — HIP vs oracle on the same (GPU-emitted) photons."""
+    W, H = 160, 90
+    scene = pkg.scenes.cornell(W, H, "cornell8d")
+    g = pkg.tracer.PhotonMap(100000).build(scene, caustics=False, seed=1)
+    gp, gw, gt = g.read()
+    o = ob.OraclePhotonMap.load(gp.astype(np.float64), gw.astype(np.float64), gt)
+    ids, t, nrm, _ = scene.PrimaryHits()
+    rid, rt, rn = ob.OracleScene(scene.flat).PrimaryHits()
+    hit = (ids >= 1) & (ids <= 5)                               # the five diffuse walls
+    cam = np.array(pkg.scenes.EYE)
+    # hit points from the oracle's float64 t: p = O + t D with D rebuilt from the camera
+    ys, xs = np.nonzero(hit)
+    c = scene.flat[0].cam
+    u, v = (xs + 0.5) / W, (ys + 0.5) / H
+    D = (np.array(c.lower_left)[None] + np.array(c.horizontal)[None] * u[:, None] + np.array(c.vertical)[None] * v[:, None]) - cam[None]
+    P = (cam[None] + D * rt[hit][:, None]).astype(np.float32)
+    N = rn[hit].astype(np.float32)
+    a = g.IrradianceEst(P, N, 0.0, 100).astype(np.float64)
+    b = o.gather(P.astype(np.float64), N.astype(np.float64), 0.0, 100)
+    close = np.isclose(a, b, rtol=2e-4, atol=1e-9).all(1)
+    assert close.mean() > 0.99
+    assert np.allclose(a.mean(0), b.mean(0), rtol=1e-3)
+    assert (a.sum(1) > 0).mean() > 0.95                          # the walls are lit
