@@ -285,24 +285,61 @@ GRT_DEV void ray_setup_unit(Ray32& r, f3 O, f3 D) {
 // the arithmetic, and the box/sphere choice is a scalar branch on one SGPR bit mask.  (Holding
 // the 8 x 7 words in SGPRs instead overflows the 102-SGPR file: the allocator spills them to
 // VGPR lanes and pays a v_readlane per operand.)
-template <int NP>
+// One object of Scene.intersect's loop (scene.go:173-178) with the accept test folded in:
+// AABB.Hit returns t0 when min(tMax, t1) > max(tMin, t0) (aabb.go:33-44) and the caller keeps it
+// when t0 > 0; Sphere.Hit returns the first root inside (tMin, tMax) (sphere.go:36-43).
+GRT_DEV void hit_update(float4 pa, float4 pb, bool is_box, int i, const Ray32& r, float bias, float& tbest, int& best) {
+  if (is_box) {
+    float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
+    float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
+    float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
+    float t0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float t1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const bool acc = (fminf(tbest, t1) > fmaxf(bias, t0)) & (t0 > 0.0f);
+    tbest = acc ? t0 : tbest;
+    best = acc ? i : best;
+  } else {
+    f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
+    float k = dot3(oc, r.D) * r.inva;
+    f3 l = fma3(r.D, -k, oc);
+    float sq = sqrt32((pb.x - dot3(l, l)) * r.inva);  // NaN when there is no real root
+    float t1 = -k - sq, t2 = -k + sq;
+    const bool in1 = (t1 > bias) & (t1 < tbest), in2 = (t2 > bias) & (t2 < tbest);
+    const float t = in1 ? t1 : t2;
+    const bool acc = (in1 | in2) & (t > 0.0f);
+    tbest = acc ? t : tbest;
+    best = acc ? i : best;
+  }
+}
+
+// Scene.intersect with the objects in LDS: the loop is fully unrolled, every lane reads the
+// same address (an LDS broadcast, no bank conflict), the record of object i+1 is requested
+// before object i is tested so its LDS latency hides behind ~20 VALU instructions, and the
+// box/sphere choice is a scalar branch on one SGPR bit mask.  (Holding the 8 x 7 words in SGPRs
+// instead overflows the 102-SGPR file: the allocator spills them to VGPR lanes and pays a
+// v_readlane per operand.)
+template <int NP, bool PREFETCH = false>
 GRT_DEV int intersect_lds(const float4* __restrict__ tp, uint32_t box_mask, const Ray32& r, float bias, float& t_out) {
   float tbest = 3.402823466e38f;
   int best = -1;
   // Records beyond n_prims are padding the host fills with a sphere of negative squared radius
   // (never hit), so the unrolled loop carries no per-object guard.
+  if (PREFETCH) {
+    float4 pa = tp[0], pb = tp[1];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const float4 pa = tp[2 * i], pb = tp[2 * i + 1];
-    float ht;
-    if ((box_mask >> i) & 1u)
-      ht = aabb_hit32<false>(pa, pb, r, bias, tbest);
-    else
-      ht = sphere_hit32(pa, pb, r, bias, tbest);
-    if (ht > 0.0f) {
-      best = i;
-      tbest = ht;
+    for (int i = 0; i < NP; ++i) {
+      float4 na = pa, nb = pb;
+      if (i + 1 < NP) {
+        na = tp[2 * i + 2];
+        nb = tp[2 * i + 3];
+      }
+      hit_update(pa, pb, (box_mask >> i) & 1u, i, r, bias, tbest, best);
+      pa = na;
+      pb = nb;
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) hit_update(tp[2 * i], tp[2 * i + 1], (box_mask >> i) & 1u, i, r, bias, tbest, best);
   }
   t_out = tbest;
   return best;
@@ -388,7 +425,7 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
 // arrays of S and the loop runs over S.n_prims.  `alive` turns false when the lane has finished
 // sample s_end-1.  n_rays counts intersect() calls (scene.go:242).
-template <int NP, bool RELOAD = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                           uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
@@ -401,7 +438,7 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
   else if (NP > 0)
-    id = intersect_lds<NP>(tp, S.box_mask, r, S.bias, t);
+    id = intersect_lds<NP, PREFETCH>(tp, S.box_mask, r, S.bias, t);
   else
     id = intersect32_t<false>(S, r, t);
   n_rays++;                                         // scene.go:242

@@ -62,7 +62,7 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
 // in the same loop iteration, so every iteration of the wave-wide loop does one intersect()
 // for every lane that still has samples left — terminated paths never leave idle lanes
 // behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
-template <int NP, bool RELOAD = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
   LaneState L;
   lane_begin(S, fx, fy, pix_key, s0, L);
   while (__any(alive)) {
-    if (alive) path_advance<NP, RELOAD>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays);
+    if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays);
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
@@ -226,8 +226,12 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
 
 // Config C2, roofline variant: `samples` jittered primary rays per pixel
 // in-kernel, FP32 only, one checksum word per pixel = sum of (id+1).  A wave owns an 8x8
-// tile so its rays are coherent.
+// tile so its rays are coherent.  NP > 0: objects in LDS, unrolled loop (as k_pathtrace).
+template <int NP, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum) {
+  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  SceneTables<NP> T;
+  load_tables<NP>(S, lds, T);
   const int lane = threadIdx.x & 63;
   const int tiles_x = (S.W + 7) >> 3, tiles_y = (S.H + 7) >> 3;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -237,13 +241,18 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
   uint32_t sum = 0;
   for (int s = 0; s < samples; ++s) {
+    if (NP > 0) asm volatile("" ::: "memory");  // re-read the objects from LDS each ray (see path_advance)
     uint32_t pk = grt_rng_path_key(pix_key, (uint32_t)s);
     f3 O, D;
     make_primary(S, x, y, grt_rng_draw(pk, GRT_DIM_JITTER_U), grt_rng_draw(pk, GRT_DIM_JITTER_V), O, D);
     Ray32 r;
     ray_setup(r, O, D);
     float t;
-    sum += (uint32_t)(intersect32(S, r, t) + 1);
+    int id;
+    if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
+    else if (NP > 0) id = intersect_lds<NP, PREFETCH>(T.tp, S.box_mask, r, S.bias, t);
+    else id = intersect32_t<false>(S, r, t);
+    sum += (uint32_t)(id + 1);
   }
   if (valid) checksum[(size_t)y * (size_t)S.W + (size_t)x] = sum;
 }

@@ -101,3 +101,32 @@ def test_grazing_and_axis_parallel_rays(pkg, ob):
         rid, rt, rn = ob.OracleScene(scene.flat).PrimaryHits()
         assert (ids == rid).all()
         assert np.abs(nrm - rn).max() < N_ABS_TOL
+
+
+def test_primary_sweep_checksum(pkg, ob):
+    """C2 roofline variant: with 1 sample the checksum is id+1 of the jittered primary ray — the
+    same ray grt_primary_hits traces in GRT_JITTER_RNG mode (FP32 ray generation here, so the few
+    silhouette pixels may differ); both kernel instances (LDS-unrolled, generic) agree exactly."""
+    import ctypes as C
+
+    import torch
+
+    scene = pkg.scenes.cornell(640, 360)
+    lib = pkg._capi.load()
+    rid, _, _ = ob.OracleScene(scene.flat).PrimaryHits(1, 1)
+    sums = []
+    for variant in (0, 1):
+        o = scene.opts(seed=1)
+        o.flags = variant
+        chk = torch.zeros(640 * 360, dtype=torch.int32, device="cuda")
+        pkg._capi.check(lib.grt_primary_sweep_dev(scene.handle, C.byref(o), 1, chk.data_ptr(), None))
+        torch.cuda.synchronize()
+        sums.append(chk.cpu().numpy().reshape(360, 640))
+    assert (sums[0] == sums[1]).all()
+    assert (sums[0] == rid + 1).mean() > 0.9995
+    o = scene.opts(seed=1)
+    chk = torch.zeros(640 * 360, dtype=torch.int32, device="cuda")
+    pkg._capi.check(lib.grt_primary_sweep_dev(scene.handle, C.byref(o), 64, chk.data_ptr(), None))
+    torch.cuda.synchronize()
+    c = chk.cpu().numpy().reshape(360, 640)
+    assert (c[rid < 0] <= 64 * 8).all() and c[180, 320] == 64 * 4   # centre pixel: the back wall, id 3

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Config C4: photon emission + kd-tree build + k-nearest radiance gather at 1920x1080.
+    python tools/bench_photon.py [--photons 1000000] [--k 100] [--rounds 5] [--cpu-queries 20000]
+Prints one JSON line.  Roofline: algorithmic bytes per query = k * 28 + 36."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("go-raytracer_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--photons", type=int, default=1000000)
+ap.add_argument("--k", type=int, default=100)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--cpu-queries", type=int, default=20000)
+a = ap.parse_args()
+W, H = a.width, a.height
+lib = pkg._capi.load()
+scene = pkg.scenes.cornell(W, H, "cornell8d")
+
+t0 = time.perf_counter()
+gmap = pkg.tracer.PhotonMap(a.photons).build(scene, caustics=False, seed=1)
+t_global = time.perf_counter() - t0
+t0 = time.perf_counter()
+cmap = pkg.tracer.PhotonMap(a.photons // 2).build(scene, caustics=True, seed=1)
+t_caustic = time.perf_counter() - t0
+
+# one query per primary hit on a diffuse wall (objects 1..5), position rebuilt from t
+ids, t, nrm, _ = scene.PrimaryHits()
+hit = (ids >= 1) & (ids <= 5)
+ys, xs = np.nonzero(hit)
+c = scene.flat[0].cam
+cam = np.array(c.origin)
+u, v = (xs + 0.5) / W, (ys + 0.5) / H
+D = np.array(c.lower_left)[None] + np.array(c.horizontal)[None] * u[:, None] + np.array(c.vertical)[None] * v[:, None] - cam[None]
+P = (cam[None] + D * t[hit].astype(np.float64)[:, None]).astype(np.float32)
+N = nrm[hit].astype(np.float32)
+nq = P.shape[0]
+dP, dN = torch.from_numpy(P).cuda(), torch.from_numpy(N).cuda()
+out = torch.empty_like(dP)
+ws = torch.empty(max(16, int(lib.grt_photon_gather_workspace_bytes(nq))), dtype=torch.uint8, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+res = {}
+for name, pm, radius in (("global_r0", gmap, 0.0), ("caustic_r1", cmap, 1.0)):
+    times = []
+    for r in range(a.rounds + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pkg._capi.check(lib.grt_photon_gather_dev(pm.handle, dP.data_ptr(), dN.data_ptr(), nq, radius, a.k, out.data_ptr(),
+                                                  ws.data_ptr(), stream))
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            times.append(e0.elapsed_time(e1))
+    times.sort()
+    ms = times[len(times) // 2]
+    bytes_q = a.k * 28 + 36
+    res[name] = {"ms": ms, "queries_per_s": nq / ms * 1e3, "algorithmic_GBps": nq * bytes_q / ms / 1e6,
+                 "frac_of_8TBps": nq * bytes_q / ms / 1e6 / 8000.0, "mean_irradiance": out.mean(0).tolist()}
+
+cpu = None
+if a.cpu_queries > 0:
+    from oracle import binding as ob
+    gp, gw, gt = gmap.read()
+    o = ob.OraclePhotonMap.load(gp.astype(np.float64), gw.astype(np.float64), gt)
+    sel = np.random.RandomState(0).choice(nq, min(a.cpu_queries, nq), replace=False)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    t0 = time.perf_counter()
+    o.gather(P[sel].astype(np.float64), N[sel].astype(np.float64), 0.0, a.k, nthreads=threads)
+    dt = time.perf_counter() - t0
+    cpu = {"queries_per_s": len(sel) / dt, "cores": threads, "kind": "port", "sample": f"{len(sel)} of the {nq} queries, k={a.k}"}
+
+print(json.dumps({
+    "workload": f"C4: cornell8d, {a.photons} global + {a.photons // 2} caustic photons, k={a.k}, {nq} primary-hit queries at {W}x{H}",
+    "emission": {"global_s": t_global, "global_emitted": gmap.emitted(), "global_stored": gmap.count(),
+                 "caustic_s": t_caustic, "caustic_emitted": cmap.emitted(), "caustic_stored": cmap.count(),
+                 "note": "wall time of grt_photon_build: emission kernels + D2H + host kd-tree build + upload"},
+    "gather": res, "cpu_baseline": cpu}))

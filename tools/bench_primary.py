@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Config C2: primary-ray intersection at 3840x2160.
+  parity variant   grt_primary_hits: 1 ray/pixel, id/t/normal out (20 B/ray), FP64 re-test of ambiguous lanes
+  roofline variant grt_primary_sweep_dev: S jittered rays/pixel in-kernel, FP32, 4 B checksum/pixel;
+                   224 flop/ray = 20 camera + 6 x 25 AABB + 2 x 27 sphere
+Prints one JSON line."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("go-raytracer_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--samples", type=int, default=256)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--variant", type=int, default=0)
+a = ap.parse_args()
+lib = pkg._capi.load()
+scene = pkg.scenes.cornell(a.width, a.height)
+ids, t, nrm, fb = scene.PrimaryHits()
+parity_ms = scene.last_kernel_ms()
+chk = torch.zeros(a.width * a.height, dtype=torch.int32, device="cuda")
+o = scene.opts(seed=1)
+o.flags = a.variant
+stream = torch.cuda.current_stream().cuda_stream
+times = []
+for r in range(a.rounds + 1):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    pkg._capi.check(lib.grt_primary_sweep_dev(scene.handle, C.byref(o), a.samples, chk.data_ptr(), stream))
+    e1.record()
+    torch.cuda.synchronize()
+    if r:
+        times.append(e0.elapsed_time(e1))
+times.sort()
+ms = times[len(times) // 2]
+rays = a.width * a.height * a.samples
+hit_frac = float((chk > 0).float().mean().item())
+print(json.dumps({
+    "workload": f"C2: cornell8 {a.width}x{a.height} aspect 16/9, primary rays only",
+    "parity_variant": {"kernel_ms": parity_ms, "rays_per_s": a.width * a.height / parity_ms * 1e3,
+                       "fp64_retest_fraction": fb / (a.width * a.height), "note": "HBM-write/launch bound; no VALU fraction quoted"},
+    "roofline_variant": {"samples_per_pixel": a.samples, "kernel_ms": ms, "rays_per_s": rays / ms * 1e3,
+                         "flop_per_ray": 224, "achieved_TFLOPs": rays * 224 / ms / 1e9, "peak_TFLOPs": 157.3,
+                         "frac": rays * 224 / ms / 1e9 / 157.3, "pixels_with_a_hit": hit_frac}}))
