@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <vector>
@@ -33,16 +34,19 @@
 #define GRT_API extern "C" __attribute__((visibility("default")))
 #define PI_F 3.14159265358979323846f
 
-// ---- photon record in HBM (kd-tree order, 1-based; 28 B per photon) ------------------------
-//   pos4[i]  = (x, y, z, bits)   bits: split axis (2 bits) | theta << 8 | phi << 16
+// ---- photon record in HBM (leaf-bucket order, 0-based; 28 B per photon) --------------------
+//   pos4[i]  = (x, y, z, bits)   bits: theta << 8 | phi << 16
 //   pow3[3i] = power r, g, b     (already scaled by 1000/max)
+//   nodes[i] = (plane, axis)     split planes, heap order, i in [1, 2^depth)
+#define KD_LEAF 64
 struct grt_pmap {
-  int n = 0, max = 0, device = 0;
+  int n = 0, max = 0, device = 0, depth = 0;
   uint64_t emitted = 0;
   float4* d_pos4 = nullptr;  // [n+1]
   float* d_pow3 = nullptr;   // [3(n+1)]
+  float2* d_nodes = nullptr; // [2^depth]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
-  std::vector<int> order;    // tree slot -> storage (emission) index, for grt_photon_read
+  std::vector<int> order;    // slot -> storage (emission) index, for grt_photon_read
 };
 
 // ---- emission ---------------------------------------------------------------------------------
@@ -167,68 +171,74 @@ __global__ __launch_bounds__(256) void k_photon_scatter(const int* __restrict__ 
   if (slot == max - 1) *last_emit = i;
 }
 
-// ---- left-balanced kd-tree (host) -----------------------------------------------------------
+// ---- bucket kd-tree (host build) ------------------------------------------------------------
+// kdtree.New(list, true) (photon_mapping.go:207) builds a balanced tree; here the balanced tree is
+// a complete binary tree of `depth` levels of split planes over the photons sorted into 2^depth
+// leaf buckets of 33..64 photons each.  Leaf j owns the contiguous slots
+// [j*n >> depth, (j+1)*n >> depth), so a wave reads a whole bucket with one coalesced load and
+// neither ranges nor child pointers are stored.  nodes[i] (heap order, children 2i and 2i+1) =
+// (plane, axis): every photon of the left subtree has coordinate <= plane, every photon of the
+// right subtree >= plane.
 struct HostPhoton {
   float p[3];
   float pw[3];
   int bits, src;
 };
-static void balance(std::vector<HostPhoton>& ph, std::vector<int>& idx, int lo, int hi, size_t node, std::vector<int>& heap,
-                    std::vector<uint8_t>& axis_of, int par_depth) {
-  const int n = hi - lo;
-  if (n <= 0) return;
-  // split axis: largest extent of the segment
+static inline int leaf_start(long long j, int n, int depth) { return (int)((j * (long long)n) >> depth); }
+
+static void kd_split(const std::vector<HostPhoton>& ph, std::vector<int>& idx, int leaf_lo, int leaf_hi, size_t node, int n,
+                     int depth, std::vector<float2>& nodes, int par_depth) {
+  if (leaf_hi - leaf_lo <= 1) return;
+  const int lo = leaf_start(leaf_lo, n, depth), hi = leaf_start(leaf_hi, n, depth);
+  const int leaf_mid = (leaf_lo + leaf_hi) >> 1, mid = leaf_start(leaf_mid, n, depth);
   float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
   for (int i = lo; i < hi; ++i)
     for (int k = 0; k < 3; ++k) {
       float v = ph[idx[i]].p[k];
       mn[k] = std::min(mn[k], v), mx[k] = std::max(mx[k], v);
     }
-  int ax = 0;
+  int ax = 0;  // split axis: largest extent of the segment
   if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
   if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
-  // size of the left subtree of a left-balanced tree with n nodes
-  int m = 1;
-  while (4 * m <= n) m *= 2;
-  const int left = (3 * m <= n) ? 2 * m - 1 : n - m;
   auto cmp = [&](int a, int b) {
     float x = ph[a].p[ax], y = ph[b].p[ax];
     return x < y || (x == y && a < b);
   };
-  std::nth_element(idx.begin() + lo, idx.begin() + lo + left, idx.begin() + hi, cmp);
-  heap[node] = idx[lo + left];
-  axis_of[node] = (uint8_t)ax;
-  if (par_depth > 0 && n > 4096) {
-    auto fut = std::async(std::launch::async, [&, lo, left, node, par_depth] {
-      balance(ph, idx, lo, lo + left, 2 * node, heap, axis_of, par_depth - 1);
+  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, cmp);
+  float2 nd;
+  nd.x = ph[idx[mid]].p[ax];  // smallest coordinate of the right part
+  nd.y = __builtin_bit_cast(float, ax);
+  nodes[node] = nd;
+  if (par_depth > 0 && hi - lo > 8192) {
+    auto fut = std::async(std::launch::async, [&, leaf_lo, leaf_mid, node, par_depth] {
+      kd_split(ph, idx, leaf_lo, leaf_mid, 2 * node, n, depth, nodes, par_depth - 1);
     });
-    balance(ph, idx, lo + left + 1, hi, 2 * node + 1, heap, axis_of, par_depth - 1);
+    kd_split(ph, idx, leaf_mid, leaf_hi, 2 * node + 1, n, depth, nodes, par_depth - 1);
     fut.get();
   } else {
-    balance(ph, idx, lo, lo + left, 2 * node, heap, axis_of, 0);
-    balance(ph, idx, lo + left + 1, hi, 2 * node + 1, heap, axis_of, 0);
+    kd_split(ph, idx, leaf_lo, leaf_mid, 2 * node, n, depth, nodes, 0);
+    kd_split(ph, idx, leaf_mid, leaf_hi, 2 * node + 1, n, depth, nodes, 0);
   }
 }
 
 static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
   const int n = (int)ph.size();
-  std::vector<int> idx(n), heap((size_t)n + 1, -1);
-  std::vector<uint8_t> axis_of((size_t)n + 1, 0);
+  int depth = 0;
+  while (((long long)KD_LEAF << depth) < n) depth++;
+  std::vector<int> idx(n);
+  std::vector<float2> nodes((size_t)1 << depth, make_float2(0.0f, 0.0f));
   for (int i = 0; i < n; ++i) idx[i] = i;
-  balance(ph, idx, 0, n, 1, heap, axis_of, 4);
+  if (n > 0) kd_split(ph, idx, 0, 1 << depth, 1, n, depth, nodes, 4);
   std::vector<float4> pos4((size_t)n + 1);
   std::vector<float> pow3(3 * ((size_t)n + 1), 0.0f);
-  pm->order.assign((size_t)n + 1, -1);
-  pos4[0] = make_float4(0, 0, 0, 0);
-  for (int i = 1; i <= n; ++i) {
-    const HostPhoton& h = ph[heap[i]];
-    int bits = (h.bits & ~3) | axis_of[i];
-    float w;
-    memcpy(&w, &bits, 4);
-    pos4[i] = make_float4(h.p[0], h.p[1], h.p[2], w);
+  pm->order.assign((size_t)n, -1);
+  for (int i = 0; i < n; ++i) {
+    const HostPhoton& h = ph[idx[i]];
+    pos4[i] = make_float4(h.p[0], h.p[1], h.p[2], __builtin_bit_cast(float, h.bits));
     pow3[3 * (size_t)i] = h.pw[0], pow3[3 * (size_t)i + 1] = h.pw[1], pow3[3 * (size_t)i + 2] = h.pw[2];
     pm->order[i] = h.src;
   }
+  pos4[n] = make_float4(0, 0, 0, 0);
   std::vector<float> lut(4 * 256);
   for (int i = 0; i < 256; ++i) {  // photon_mapping.go:105-111
     double angle = (double)i * (1.0 / 256.0) * M_PI;
@@ -236,12 +246,15 @@ static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
     lut[512 + i] = (float)cos(2.0 * angle), lut[768 + i] = (float)sin(2.0 * angle);
   }
   pm->n = n;
+  pm->depth = depth;
   GRT_HIP(hipMalloc(&pm->d_pos4, pos4.size() * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_pow3, pow3.size() * sizeof(float)));
   GRT_HIP(hipMalloc(&pm->d_lut, lut.size() * sizeof(float)));
+  GRT_HIP(hipMalloc(&pm->d_nodes, nodes.size() * sizeof(float2)));
   GRT_HIP(hipMemcpy(pm->d_pos4, pos4.data(), pos4.size() * sizeof(float4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(pm->d_pow3, pow3.data(), pow3.size() * sizeof(float), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(pm->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(pm->d_nodes, nodes.data(), nodes.size() * sizeof(float2), hipMemcpyHostToDevice));
   return GRT_OK;
 }
 
@@ -407,7 +420,7 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
   std::vector<float> w3(3 * (n + 1));
   GRT_HIP(hipMemcpy(p4.data(), pm->d_pos4, p4.size() * sizeof(float4), hipMemcpyDeviceToHost));
   GRT_HIP(hipMemcpy(w3.data(), pm->d_pow3, w3.size() * sizeof(float), hipMemcpyDeviceToHost));
-  for (size_t i = 1; i <= n; ++i) {  // back to storage (emission) order
+  for (size_t i = 0; i < n; ++i) {  // back to storage (emission) order
     const size_t d = (size_t)pm->order[i];
     int bits;
     memcpy(&bits, &p4[i].w, 4);
@@ -424,177 +437,274 @@ GRT_API void grt_photon_free(grt_pmap* pm) {
     (void)hipFree(pm->d_pos4);
     (void)hipFree(pm->d_pow3);
     (void)hipFree(pm->d_lut);
+    (void)hipFree(pm->d_nodes);
   }
   delete pm;
 }
 
-// ---- k-nearest gather -----------------------------------------------------------------------
-// The top TOP_NODES nodes of the tree (10 levels) are copied to LDS by every workgroup: every
-// query walks through them, deeper nodes are read from HBM / L2.
-#define TOP_NODES 1024
-#define GATHER_BLOCK 64
+// ---- k-nearest gather: one wave per query --------------------------------------------------
+// IrradianceEst (photon_mapping.go:125-162).  A WAVE serves one query at a time:
+//   - the walk down the split planes is wave-uniform (node index, stack and bound live in
+//     SGPRs, the stack is two VGPRs indexed by lane: push = v_cndmask on lane == sp, pop = v_readlane); the top
+//     GATHER_TOP_NODES planes are read from an LDS copy, deeper ones by scalar loads;
+//   - a leaf bucket is ONE coalesced load: lane l tests photon start+l;
+//   - photons within the current bound are appended to the wave's candidate pool in LDS
+//     (ballot + mbcnt compaction).  NearestSet + NKeeper(k) (photon_mapping.go:131-133) becomes a
+//     selection of the k-th smallest squared distance in the pool: 31 steps of bisection on the
+//     float bits, each step one v_cmp + s_bcnt1 per pool register.  The selection runs when the
+//     pool first holds k photons (the first finite bound), when the pool is full (then the pool
+//     is compacted to the photons within the new bound) and once at the end;
+//   - consecutive queries of a wave are neighbours when the caller passes them in image order,
+//     and the k-th distance is 1-Lipschitz: (r_k(previous) + |q - previous|)^2 is a valid bound
+//     from the first node on, so most queries run exactly one selection;
+//   - the loop of photon_mapping.go:138-161 runs over the pool, one candidate per lane, and a
+//     wave reduction produces the sums.
+// Exact: every photon with d^2 <= (k-th smallest d^2) is accepted, as in the oracle.
+#define GATHER_TOP_NODES 1024
+#define GATHER_WAVES 4
 
-struct TreeView {
+GRT_DEV float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+GRT_DEV float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+GRT_DEV int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+GRT_DEV int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+GRT_DEV float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+GRT_DEV bool uniform_true(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+struct KdView {
+  const float2* __restrict__ nodes;
   const float4* __restrict__ pos4;
-  const float4* top;  // LDS copy of pos4[0 .. TOP_NODES)
-  int n;
+  const float* __restrict__ pow3;
+  const float* __restrict__ lut;
+  int n, depth;
 };
-GRT_DEV float4 node_at(const TreeView& T, int i) { return i < TOP_NODES ? T.top[i] : T.pos4[i]; }
 
-// Stackless walk of the implicit left-balanced tree in the order near subtree, node, far
-// subtree.  visit(i, node, d2) is called once per visited node; bound() returns the current
-// pruning radius^2.  State is (cur, last): the parent is cur >> 1, so no stack is needed.
-template <class Visit, class Bound>
-GRT_DEV void kd_walk(const TreeView& T, f3 q, Visit visit, Bound bound) {
-  int cur = 1, last = 0;
-  while (cur >= 1) {
-    const float4 nd = node_at(T, cur);
-    const int ax = __float_as_int(nd.w) & 3;
-    const float delta = (ax == 0 ? q.x - nd.x : (ax == 1 ? q.y - nd.y : q.z - nd.z));
-    const int nearc = 2 * cur + (delta < 0.0f ? 0 : 1), farc = 2 * cur + (delta < 0.0f ? 1 : 0);
-    bool do_visit = false;
-    if (last == (cur >> 1)) {        // arrived from the parent
-      if (nearc <= T.n) {
-        last = cur, cur = nearc;
-        continue;
-      }
-      do_visit = true;
-    } else if (last == nearc) {      // back from the near subtree
-      do_visit = true;
-    }
-    if (do_visit) {
-      const float dx = nd.x - q.x, dy = nd.y - q.y, dz = nd.z - q.z;
-      visit(cur, nd, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-      if (farc <= T.n && delta * delta <= bound()) {
-        last = cur, cur = farc;
-        continue;
-      }
-    }
-    last = cur, cur >>= 1;           // done with this subtree
+// k-th smallest (1-based) of the pool's squared distances, as float bits.  v[r] holds the bits
+// of entry lane + 64 r (0xffffffff beyond the pool).  Squared distances are non-negative, so
+// their bit patterns order like unsigned integers.
+template <int RMAX>
+GRT_DEV uint32_t select_kth(const uint32_t (&v)[RMAX], int k) {
+  uint32_t T = 0;
+#pragma unroll 1
+  for (int bit = 30; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[r] < cand));
+    if (c < k) T = cand;
   }
+  return T;
 }
 
-// Pass 1: squared distance of the k-th nearest photon.  Max-heap of k floats per lane in LDS,
-// slot j of lane t at heap[j * GATHER_BLOCK + t] (conflict-free when lanes agree on j).
-__global__ __launch_bounds__(GATHER_BLOCK) void k_knn_radius(const float4* __restrict__ pos4, int n_photons,
-                                                             const float* __restrict__ qpos, int n_q, int k,
-                                                             float* __restrict__ rk2_out) {
-  extern __shared__ float4 smem4[];
-  float4* top = smem4;
-  float* heap = (float*)(smem4 + TOP_NODES);
-  for (int i = threadIdx.x; i < TOP_NODES; i += GATHER_BLOCK) top[i] = i <= n_photons ? pos4[i] : make_float4(0, 0, 0, 0);
+template <int RMAX>
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather_knn(KdView T, const float* __restrict__ qpos,
+                                                                  const float* __restrict__ qnrm, int n_q, int q_per_wave,
+                                                                  float radius, int k, float* __restrict__ irrad,
+                                                                  float* __restrict__ rk2_out) {
+  constexpr int CAP = 64 * RMAX;
+  __shared__ float2 top[GATHER_TOP_NODES];
+  __shared__ float pool_d2[GATHER_WAVES][CAP];
+  __shared__ int pool_ix[GATHER_WAVES][CAP];
+  const int leaf_base = 1 << T.depth;
+  const int lds_end = min(leaf_base, GATHER_TOP_NODES);
+  for (int i = threadIdx.x; i < GATHER_TOP_NODES; i += blockDim.x) top[i] = i < leaf_base ? T.nodes[i] : make_float2(0.0f, 0.0f);
   __syncthreads();
-  const int qi = blockIdx.x * GATHER_BLOCK + threadIdx.x;
-  if (qi >= n_q) return;
-  TreeView T = {pos4, top, n_photons};
-  const f3 q = mk3(qpos[3 * (size_t)qi], qpos[3 * (size_t)qi + 1], qpos[3 * (size_t)qi + 2]);
-  float* h = heap + threadIdx.x;
-  int hn = 0;
-  float hmax = 3.402823466e38f;  // pruning bound: +inf until the heap is full
-  kd_walk(
-      T, q,
-      [&](int, const float4&, float d2) {
-        if (hn < k) {  // sift up
-          int i = hn++;
-          while (i > 0) {
-            int p = (i - 1) >> 1;
-            float pv = h[p * GATHER_BLOCK];
-            if (pv >= d2) break;
-            h[i * GATHER_BLOCK] = pv;
-            i = p;
-          }
-          h[i * GATHER_BLOCK] = d2;
-          if (hn == k) hmax = h[0];
-        } else if (d2 < hmax) {  // replace the root, sift down
-          int i = 0;
-          for (;;) {
-            int l = 2 * i + 1, r = l + 1, b = i;
-            float bv = d2;
-            if (l < k) {
-              float lv = h[l * GATHER_BLOCK];
-              if (lv > bv) b = l, bv = lv;
-            }
-            if (r < k) {
-              float rv = h[r * GATHER_BLOCK];
-              if (rv > bv) b = r, bv = rv;
-            }
-            if (b == i) break;
-            h[i * GATHER_BLOCK] = bv;
-            i = b;
-          }
-          h[i * GATHER_BLOCK] = d2;
-          hmax = h[0];
-        }
-      },
-      [&]() { return hmax; });
-  float rk2 = 0.0f;
-  if (hn == k) rk2 = h[0];
-  else
-    for (int i = 0; i < hn; ++i) rk2 = fmaxf(rk2, h[i * GATHER_BLOCK]);  // fewer than k photons: all of them
-  rk2_out[qi] = hn ? rk2 : -1.0f;
-}
-
-// Pass 2: IrradianceEst's loop over the k nearest (photon_mapping.go:138-161): every photon
-// with d2 <= rk2, radius filter, direction test against the LUT direction, power sum,
-// r2 = largest accepted d2, found < 8 -> unscaled sum.
-__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(const float4* __restrict__ pos4, const float* __restrict__ pow3,
-                                                         const float* __restrict__ lut, int n_photons,
-                                                         const float* __restrict__ qpos, const float* __restrict__ qnrm, int n_q,
-                                                         float radius, const float* __restrict__ rk2_in,
-                                                         float* __restrict__ irrad) {
-  extern __shared__ float4 smem4[];
-  float4* top = smem4;
-  for (int i = threadIdx.x; i < TOP_NODES; i += GATHER_BLOCK) top[i] = i <= n_photons ? pos4[i] : make_float4(0, 0, 0, 0);
-  __syncthreads();
-  const int qi = blockIdx.x * GATHER_BLOCK + threadIdx.x;
-  if (qi >= n_q) return;
-  TreeView T = {pos4, top, n_photons};
-  const f3 q = mk3(qpos[3 * (size_t)qi], qpos[3 * (size_t)qi + 1], qpos[3 * (size_t)qi + 2]);
-  const f3 nr = mk3(qnrm[3 * (size_t)qi], qnrm[3 * (size_t)qi + 1], qnrm[3 * (size_t)qi + 2]);
-  const float rk2 = rk2_in[qi];
+  const int lane = threadIdx.x & 63;
+  const int wave = sgpr(threadIdx.x >> 6);
+  float* pd2 = pool_d2[wave];
+  int* pix = pool_ix[wave];
+  const int q0 = (blockIdx.x * GATHER_WAVES + wave) * q_per_wave;
+  const int q1 = min(q0 + q_per_wave, n_q);
   const float radius2 = radius * radius;
-  f3 sum = mk3(0, 0, 0);
-  float r2 = 0.0f;
-  int found = 0;
-  if (rk2 >= 0.0f)
-    kd_walk(
-        T, q,
-        [&](int i, const float4& nd, float d2) {
-          if (d2 > rk2) return;
-          if (radius == 0.0f || d2 < radius2) {  // photon_mapping.go:141
-            const int bits = __float_as_int(nd.w);
-            const int th = (bits >> 8) & 255, ph = (bits >> 16) & 255;
-            const float st = lut[256 + th];
-            const float dx = st * lut[512 + ph], dy = st * lut[768 + ph], dz = lut[th];  // PhotonDir, :117-122
-            if (dx * nr.x + dy * nr.y + dz * nr.z < 0.0f) {                           // :144
-              sum.x += pow3[3 * (size_t)i], sum.y += pow3[3 * (size_t)i + 1], sum.z += pow3[3 * (size_t)i + 2];
-              r2 = fmaxf(r2, d2);
-              found++;
-            }
+  float prev_rk = -1.0f, pqx = 0.0f, pqy = 0.0f, pqz = 0.0f;  // k-th distance of the previous query (if it had one)
+
+  for (int qi = q0; qi < q1; ++qi) {
+    const float qx = qpos[3 * (size_t)qi], qy = qpos[3 * (size_t)qi + 1], qz = qpos[3 * (size_t)qi + 2];
+    float bound = radius > 0.0f ? radius2 : INFINITY;  // photons beyond the radius never count (:141)
+    bool tight = false;                                // bound comes from k photons already seen
+    if (prev_rk >= 0.0f) {
+      const float dx = qx - pqx, dy = qy - pqy, dz = qz - pqz;
+      const float r = prev_rk + sqrt32(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+      const float b = r * r * 1.0001f;
+      if (b < bound) bound = b, tight = true;
+    }
+    int count = 0;
+    uint32_t vb[RMAX];
+
+    // refresh the bound from the pool; compact the pool when it is full
+    auto reselect = [&](bool compact) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int j = lane + 64 * r;
+        vb[r] = j < count ? __float_as_uint(pd2[j]) : 0xffffffffu;
+      }
+      const uint32_t Tk = select_kth<RMAX>(vb, k);
+      bound = __uint_as_float(Tk);
+      tight = true;
+      if (compact) {
+        int nc = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const int j = lane + 64 * r;
+          const bool keep = vb[r] <= Tk;
+          const int ix = pix[j];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+          const int slot = nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+          if (keep) {
+            pd2[slot] = __uint_as_float(vb[r]);
+            pix[slot] = ix;
           }
-        },
-        [&]() { return rk2; });
-  if (found >= 8) {  // :154-161
-    const float tmp = 1.0f / (PI_F * r2);
-    sum = sum * tmp;
+          nc += __builtin_popcountll(m);
+        }
+        count = nc;
+      }
+    };
+
+    if (T.n > 0) {
+      // wave-uniform walk: near child first, far child pushed with its plane distance
+      int stk_node = 0;
+      float stk_d2 = 0.0f;
+      int sp = 0, node = 1;
+      for (;;) {
+        // descend: the index only grows, so the LDS-resident levels come first
+#define GRT_KD_STEP(ND)                                                                   \
+  {                                                                                       \
+    const float2 nd = (ND);                                                               \
+    const int ax = sgpr(__float_as_int(nd.y));                                            \
+    const float qa = ax == 0 ? qx : (ax == 1 ? qy : qz);                                  \
+    const float delta = qa - nd.x;                                                        \
+    const int right = sgpr(__float_as_int(delta)) >= 0 ? 1 : 0;                           \
+    const float dd = delta * delta;                                                       \
+    if (uniform_true(dd <= bound)) {                                                      \
+      const bool top_lane = lane == sp; /* lane sp of the two stack registers */          \
+      stk_node = top_lane ? 2 * node + (right ^ 1) : stk_node;                            \
+      stk_d2 = top_lane ? dd : stk_d2;                                                    \
+      sp++;                                                                               \
+    }                                                                                     \
+    node = 2 * node + right;                                                              \
   }
-  irrad[3 * (size_t)qi] = sum.x, irrad[3 * (size_t)qi + 1] = sum.y, irrad[3 * (size_t)qi + 2] = sum.z;
+        while (node < lds_end) GRT_KD_STEP(top[node]);
+        while (node < leaf_base) GRT_KD_STEP(T.nodes[node]);
+#undef GRT_KD_STEP
+        {  // leaf bucket: one photon per lane
+          const int leaf = node - leaf_base;
+          const int a = (int)(((long long)leaf * (long long)T.n) >> T.depth);
+          const int b = (int)(((long long)(leaf + 1) * (long long)T.n) >> T.depth);
+          const int i = a + lane;
+          const bool valid = i < b;
+          const float4 p = T.pos4[valid ? i : a];
+          const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          const bool pass = valid & (d2 <= bound);
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+          if (m) {
+            const int slot = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (pass) {
+              pd2[slot] = d2;
+              pix[slot] = i;
+            }
+            count += __builtin_popcountll(m);
+            if (count > CAP - 64) reselect(true);
+            else if (!tight && count >= k) reselect(false);
+          }
+        }
+        bool more = false;
+        while (sp > 0) {  // next far subtree still within the bound
+          sp--;
+          const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(stk_d2), sp));
+          if (uniform_true(d <= bound)) {
+            node = __builtin_amdgcn_readlane(stk_node, sp);
+            more = true;
+            break;
+          }
+        }
+        if (!more) break;
+      }
+    }
+
+    // final selection, then the loop of photon_mapping.go:138-161 over the pool
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int j = lane + 64 * r;
+      vb[r] = j < count ? __float_as_uint(pd2[j]) : 0xffffffffu;
+    }
+    uint32_t Tk = 0x7f800000u;  // fewer than k photons: all of them
+    if (count >= k) Tk = select_kth<RMAX>(vb, k);
+    const float nx = qnrm[3 * (size_t)qi], ny = qnrm[3 * (size_t)qi + 1], nz = qnrm[3 * (size_t)qi + 2];
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, r2 = 0.0f;
+    int found = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int j = lane + 64 * r;
+      if (64 * r >= count) break;  // wave-uniform
+      const float d2 = __uint_as_float(vb[r]);
+      if (j < count && vb[r] <= Tk && (radius == 0.0f || d2 < radius2)) {  // :141
+        const int ix = pix[j];
+        const int bits = __float_as_int(T.pos4[ix].w);
+        const int th = (bits >> 8) & 255, ph = (bits >> 16) & 255;
+        const float st = T.lut[256 + th];
+        const float dx = st * T.lut[512 + ph], dy = st * T.lut[768 + ph], dz = T.lut[th];  // PhotonDir, :117-122
+        if (dx * nx + dy * ny + dz * nz < 0.0f) {                                       // :144
+          sx += T.pow3[3 * (size_t)ix], sy += T.pow3[3 * (size_t)ix + 1], sz += T.pow3[3 * (size_t)ix + 2];
+          r2 = fmaxf(r2, d2);
+          found++;
+        }
+      }
+    }
+    sx = wave_sum_f(sx), sy = wave_sum_f(sy), sz = wave_sum_f(sz);
+    r2 = wave_max_f(r2);
+    found = wave_sum_i(found);
+    if (found >= 8) {  // :154-161
+      const float tmp = 1.0f / (PI_F * r2);
+      sx *= tmp, sy *= tmp, sz *= tmp;
+    }
+    if (lane == 0) {
+      irrad[3 * (size_t)qi] = sx, irrad[3 * (size_t)qi + 1] = sy, irrad[3 * (size_t)qi + 2] = sz;
+      if (rk2_out) rk2_out[qi] = count >= k ? __uint_as_float(Tk) : (count ? INFINITY : -1.0f);
+    }
+    // The bound handed to the next query must be the true k-th distance over ALL photons: it is
+    // when the selection saw k photons and was not cut short by the radius.
+    if (count >= k) prev_rk = sqrt32(__uint_as_float(Tk)) * 1.00001f, pqx = qx, pqy = qy, pqz = qz;
+    else prev_rk = -1.0f;
+  }
 }
 
 #define GRT_GATHER_MAX_K 512
 
 GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (uint64_t)n * sizeof(float) : 0; }
 
+// Queries served back to back by one wave (they share the carried bound).  GRT_GATHER_QPW
+// overrides the default for tuning runs (tools/bench_photon.py).
+static int gather_qpw() {
+  const char* e = getenv("GRT_GATHER_QPW");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 16;
+}
+
 static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
                          float* d_rk2, hipStream_t st) {
-  const unsigned grid = (unsigned)((n + GATHER_BLOCK - 1) / GATHER_BLOCK);
-  const size_t lds1 = TOP_NODES * sizeof(float4) + (size_t)k * GATHER_BLOCK * sizeof(float);
-  if (lds1 > 64 * 1024)
-    GRT_HIP(hipFuncSetAttribute((const void*)k_knn_radius, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-  hipLaunchKernelGGL(k_knn_radius, dim3(grid), dim3(GATHER_BLOCK), lds1, st, (const float4*)pm->d_pos4, pm->n, d_pos, n, k, d_rk2);
-  GRT_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), TOP_NODES * sizeof(float4), st, (const float4*)pm->d_pos4,
-                     (const float*)pm->d_pow3, (const float*)pm->d_lut, pm->n, d_pos, d_nrm, n, radius, (const float*)d_rk2, d_irrad);
+  const int qpw = gather_qpw();
+  const unsigned grid = (unsigned)((n + GATHER_WAVES * qpw - 1) / (GATHER_WAVES * qpw));
+  KdView T = {pm->d_nodes, pm->d_pos4, pm->d_pow3, pm->d_lut, pm->n, pm->depth};
+  if (k <= 128)
+    hipLaunchKernelGGL(k_gather_knn<5>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
+  else if (k <= 256)
+    hipLaunchKernelGGL(k_gather_knn<9>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
+  else
+    hipLaunchKernelGGL(k_gather_knn<17>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
 }
@@ -605,13 +715,13 @@ static int gather_check(const grt_pmap* pm, const void* a, const void* b, const 
   return GRT_OK;
 }
 
-// d_workspace: grt_photon_gather_workspace_bytes(n) bytes of device memory (the per-query k-th
-// distance handed from pass 1 to pass 2).
+// d_workspace: optional, grt_photon_gather_workspace_bytes(n) bytes of device memory; when given
+// it receives the squared distance of each query's k-th nearest photon (+inf: fewer than k
+// photons in reach, -1: none).
 GRT_API int grt_photon_gather_dev(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int32_t n, float radius, int32_t k,
                                   float* d_irrad, void* d_workspace, void* stream) {
   int rc = gather_check(pm, d_pos, d_nrm, d_irrad, n, k);
   if (rc) return rc;
-  if (!d_workspace) return grt_fail(GRT_EINVAL, "grt_photon_gather_dev: NULL workspace");
   if (n == 0) return GRT_OK;
   return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream);
 }
@@ -622,20 +732,19 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
   if (rc) return rc;
   if (n == 0) return GRT_OK;
   GRT_HIP(hipSetDevice(pm->device));
-  float *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr, *d_rk2 = nullptr;
+  float *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr;
   const size_t b3 = (size_t)n * 3 * sizeof(float);
   rc = GRT_OK;
   do {
     PTRY(hipMalloc(&d_pos, b3));
     PTRY(hipMalloc(&d_nrm, b3));
     PTRY(hipMalloc(&d_out, b3));
-    PTRY(hipMalloc(&d_rk2, (size_t)n * sizeof(float)));
     PTRY(hipMemcpy(d_pos, pos, b3, hipMemcpyHostToDevice));
     PTRY(hipMemcpy(d_nrm, nrm, b3, hipMemcpyHostToDevice));
-    rc = gather_launch(pm, d_pos, d_nrm, n, radius, k, d_out, d_rk2, nullptr);
+    rc = gather_launch(pm, d_pos, d_nrm, n, radius, k, d_out, nullptr, nullptr);
     if (rc) break;
     PTRY(hipMemcpy(irrad, d_out, b3, hipMemcpyDeviceToHost));
   } while (0);
-  (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out), (void)hipFree(d_rk2);
+  (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out);
   return rc;
 }

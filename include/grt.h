@@ -177,7 +177,8 @@ int grt_primary_sweep_dev(grt_scene* scene, const grt_opts* opts, int32_t sample
 /* mapPhotons for ONE map (scene.go:140-165) + ScalePhotonPower(1000/max)
  * (photon_mapping.go:197-209): emits photons from every light until max_photons are
  * stored, caustics != 0 selects the caustic filter (scene.go:359-363,375) and power
- * (1,1,1) instead of (15,15,15).  Builds a left-balanced kd-tree on the device. */
+ * (1,1,1) instead of (15,15,15).  Builds the balanced bucket kd-tree (kdtree.New(list, true),
+ * photon_mapping.go:207) and stages it with the photons in HBM. */
 int grt_photon_build(grt_scene* scene, const grt_opts* opts, int32_t max_photons, int32_t caustics,
                      grt_pmap** out);
 int32_t grt_photon_count(const grt_pmap* pmap);
@@ -198,8 +199,9 @@ int grt_photon_load(const grt_opts* opts, const float* pos, const float* power,
  * k <= 512.  Host buffers: pos_xyz[n*3], nrm_xyz[n*3], irrad_rgb[n*3]. */
 int grt_photon_gather(const grt_pmap* pmap, const float* pos_xyz, const float* nrm_xyz, int32_t n,
                       float radius, int32_t k, float* irrad_rgb);
-/* Device-pointer variant: enqueues on `stream`, allocates nothing; d_workspace holds
- * grt_photon_gather_workspace_bytes(n) bytes (per-query k-th distance between the passes). */
+/* Device-pointer variant: enqueues on `stream`, allocates nothing.  d_workspace may be NULL;
+ * when given it holds grt_photon_gather_workspace_bytes(n) bytes and receives, per query, the
+ * squared distance of the k-th nearest photon (+inf: fewer than k in reach, -1: none). */
 int grt_photon_gather_dev(const grt_pmap* pmap, const float* d_pos_xyz, const float* d_nrm_xyz,
                           int32_t n, float radius, int32_t k, float* d_irrad_rgb,
                           void* d_workspace, void* stream);
