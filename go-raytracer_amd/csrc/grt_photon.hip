@@ -4,11 +4,10 @@
 //                    + Store's direction quantisation                photon_mapping.go:165-193
 //   k_photon_scatter ordered compaction of the stored photons + ScalePhotonPower's scale
 //                    (photon_mapping.go:197-206)
-//   balance()        kdtree.New(list, true) (photon_mapping.go:207): a left-balanced kd-tree in
-//                    implicit heap order (children of node i are 2i and 2i+1, no pointers)
-//   k_knn_radius     NearestSet + NKeeper(k) (photon_mapping.go:131-133): squared distance of
-//                    the k-th nearest photon, per query
-//   k_gather         the loop of IrradianceEst (photon_mapping.go:138-161)
+//   upload_tree()    kdtree.New(list, true) (photon_mapping.go:207): balanced median splits into
+//                    leaf buckets, collapsed to a 64-ary tree of bounding boxes
+//   k_gather_knn     NearestSet + NKeeper(k) (photon_mapping.go:131-133) and the loop of
+//                    IrradianceEst (photon_mapping.go:138-161), one wave per query
 //
 // PARITY UNPINNED for this path: the reference never runs it and the tree is
 // gonum's.  The definitions used where the source leaves room are those of
@@ -22,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
@@ -35,16 +35,18 @@
 #define PI_F 3.14159265358979323846f
 
 // ---- photon record in HBM (leaf-bucket order, 0-based; 28 B per photon) --------------------
-//   pos4[i]  = (x, y, z, bits)   bits: theta << 8 | phi << 16
-//   pow3[3i] = power r, g, b     (already scaled by 1000/max)
-//   nodes[i] = (plane, axis)     split planes, heap order, i in [1, 2^depth)
+//   pos3[3i] = x, y, z           what the search reads: a leaf bucket is 64 x 12 B, contiguous
+//   pwb[i]   = (r, g, b, bits)   what an accepted photon adds: power (already scaled by
+//                                1000/max) and direction bytes, bits = theta << 8 | phi << 16
+//   boxes[i], boxes[n_boxes+i]  min / max corners of the 64-ary tree's node boxes (see upload_tree)
 #define KD_LEAF 64
+#define KD_FAN_BITS 6
 struct grt_pmap {
-  int n = 0, max = 0, device = 0, depth = 0;
+  int n = 0, max = 0, device = 0, depth = 0, levels = 1, b0 = 0, n_boxes = 0;
   uint64_t emitted = 0;
-  float4* d_pos4 = nullptr;  // [n+1]
-  float* d_pow3 = nullptr;   // [3(n+1)]
-  float2* d_nodes = nullptr; // [2^depth]
+  float* d_pos3 = nullptr;   // [3(n+1)]
+  float4* d_pwb = nullptr;   // [n+1]
+  float4* d_boxes = nullptr; // [2 * n_boxes]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
   std::vector<int> order;    // slot -> storage (emission) index, for grt_photon_read
 };
@@ -172,13 +174,16 @@ __global__ __launch_bounds__(256) void k_photon_scatter(const int* __restrict__ 
 }
 
 // ---- bucket kd-tree (host build) ------------------------------------------------------------
-// kdtree.New(list, true) (photon_mapping.go:207) builds a balanced tree; here the balanced tree is
-// a complete binary tree of `depth` levels of split planes over the photons sorted into 2^depth
-// leaf buckets of 33..64 photons each.  Leaf j owns the contiguous slots
+// kdtree.New(list, true) (photon_mapping.go:207) builds a balanced tree; here the balanced
+// tree is `depth` levels of median splits (axis of largest extent) that sort the photons into
+// 2^depth leaf buckets of 33..64 photons.  Leaf j owns the contiguous slots
 // [j*n >> depth, (j+1)*n >> depth), so a wave reads a whole bucket with one coalesced load and
-// neither ranges nor child pointers are stored.  nodes[i] (heap order, children 2i and 2i+1) =
-// (plane, axis): every photon of the left subtree has coordinate <= plane, every photon of the
-// right subtree >= plane.
+// neither ranges nor child pointers are stored.  The split planes themselves are not kept:
+// the tree is collapsed to 64-ary nodes whose children carry their bounding boxes (a box is a
+// tighter bound than the last split plane, and 64 boxes are tested by one wave instruction
+// stream).  Level l holds 2^(b0 + 6 l) boxes, b0 = depth - 6 (levels - 1); the last level's
+// boxes are the leaves'.  boxes[i] = (min.xyz, 0), boxes[n_boxes + i] = (max.xyz, 0), levels
+// concatenated, so the first GATHER_LDS_BOXES records (the top levels) are one LDS copy.
 struct HostPhoton {
   float p[3];
   float pw[3];
@@ -186,8 +191,8 @@ struct HostPhoton {
 };
 static inline int leaf_start(long long j, int n, int depth) { return (int)((j * (long long)n) >> depth); }
 
-static void kd_split(const std::vector<HostPhoton>& ph, std::vector<int>& idx, int leaf_lo, int leaf_hi, size_t node, int n,
-                     int depth, std::vector<float2>& nodes, int par_depth) {
+static void kd_split(const std::vector<HostPhoton>& ph, std::vector<int>& idx, int leaf_lo, int leaf_hi, int n, int depth,
+                     int par_depth) {
   if (leaf_hi - leaf_lo <= 1) return;
   const int lo = leaf_start(leaf_lo, n, depth), hi = leaf_start(leaf_hi, n, depth);
   const int leaf_mid = (leaf_lo + leaf_hi) >> 1, mid = leaf_start(leaf_mid, n, depth);
@@ -205,19 +210,14 @@ static void kd_split(const std::vector<HostPhoton>& ph, std::vector<int>& idx, i
     return x < y || (x == y && a < b);
   };
   std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, cmp);
-  float2 nd;
-  nd.x = ph[idx[mid]].p[ax];  // smallest coordinate of the right part
-  nd.y = __builtin_bit_cast(float, ax);
-  nodes[node] = nd;
   if (par_depth > 0 && hi - lo > 8192) {
-    auto fut = std::async(std::launch::async, [&, leaf_lo, leaf_mid, node, par_depth] {
-      kd_split(ph, idx, leaf_lo, leaf_mid, 2 * node, n, depth, nodes, par_depth - 1);
-    });
-    kd_split(ph, idx, leaf_mid, leaf_hi, 2 * node + 1, n, depth, nodes, par_depth - 1);
+    auto fut = std::async(std::launch::async,
+                          [&, leaf_lo, leaf_mid, par_depth] { kd_split(ph, idx, leaf_lo, leaf_mid, n, depth, par_depth - 1); });
+    kd_split(ph, idx, leaf_mid, leaf_hi, n, depth, par_depth - 1);
     fut.get();
   } else {
-    kd_split(ph, idx, leaf_lo, leaf_mid, 2 * node, n, depth, nodes, 0);
-    kd_split(ph, idx, leaf_mid, leaf_hi, 2 * node + 1, n, depth, nodes, 0);
+    kd_split(ph, idx, leaf_lo, leaf_mid, n, depth, 0);
+    kd_split(ph, idx, leaf_mid, leaf_hi, n, depth, 0);
   }
 }
 
@@ -225,20 +225,44 @@ static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
   const int n = (int)ph.size();
   int depth = 0;
   while (((long long)KD_LEAF << depth) < n) depth++;
+  const int levels = std::max(1, (depth + KD_FAN_BITS - 1) / KD_FAN_BITS);
+  const int b0 = depth - KD_FAN_BITS * (levels - 1);
   std::vector<int> idx(n);
-  std::vector<float2> nodes((size_t)1 << depth, make_float2(0.0f, 0.0f));
   for (int i = 0; i < n; ++i) idx[i] = i;
-  if (n > 0) kd_split(ph, idx, 0, 1 << depth, 1, n, depth, nodes, 4);
-  std::vector<float4> pos4((size_t)n + 1);
-  std::vector<float> pow3(3 * ((size_t)n + 1), 0.0f);
+  if (n > 0) kd_split(ph, idx, 0, 1 << depth, n, depth, 4);
+  std::vector<float> pos3(3 * ((size_t)n + 1), 0.0f);
+  std::vector<float4> pwb((size_t)n + 1);
   pm->order.assign((size_t)n, -1);
   for (int i = 0; i < n; ++i) {
     const HostPhoton& h = ph[idx[i]];
-    pos4[i] = make_float4(h.p[0], h.p[1], h.p[2], __builtin_bit_cast(float, h.bits));
-    pow3[3 * (size_t)i] = h.pw[0], pow3[3 * (size_t)i + 1] = h.pw[1], pow3[3 * (size_t)i + 2] = h.pw[2];
+    pos3[3 * (size_t)i] = h.p[0], pos3[3 * (size_t)i + 1] = h.p[1], pos3[3 * (size_t)i + 2] = h.p[2];
+    pwb[i] = make_float4(h.pw[0], h.pw[1], h.pw[2], __builtin_bit_cast(float, h.bits));
     pm->order[i] = h.src;
   }
-  pos4[n] = make_float4(0, 0, 0, 0);
+  pwb[n] = make_float4(0, 0, 0, 0);
+  // boxes, bottom level first (leaves), then unions of 64 children going up
+  std::vector<size_t> off(levels);
+  size_t total = 0;
+  for (int l = 0; l < levels; ++l) off[l] = total, total += (size_t)1 << (b0 + KD_FAN_BITS * l);
+  std::vector<float4> boxes(2 * total);
+  for (long long j = 0; j < (1ll << depth); ++j) {
+    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};  // an empty leaf is never within any bound
+    for (int i = leaf_start(j, n, depth); i < leaf_start(j + 1, n, depth); ++i) {
+      for (int c = 0; c < 3; ++c) mn[c] = std::min(mn[c], pos3[3 * (size_t)i + c]), mx[c] = std::max(mx[c], pos3[3 * (size_t)i + c]);
+    }
+    boxes[off[levels - 1] + j] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+    boxes[total + off[levels - 1] + j] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+  }
+  for (int l = levels - 2; l >= 0; --l)
+    for (size_t i = 0; i < ((size_t)1 << (b0 + KD_FAN_BITS * l)); ++i) {
+      float4 mn = make_float4(3e38f, 3e38f, 3e38f, 0.0f), mx = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);
+      for (size_t c = i << KD_FAN_BITS; c < ((i + 1) << KD_FAN_BITS); ++c) {
+        const float4 a = boxes[off[l + 1] + c], b = boxes[total + off[l + 1] + c];
+        mn.x = std::min(mn.x, a.x), mn.y = std::min(mn.y, a.y), mn.z = std::min(mn.z, a.z);
+        mx.x = std::max(mx.x, b.x), mx.y = std::max(mx.y, b.y), mx.z = std::max(mx.z, b.z);
+      }
+      boxes[off[l] + i] = mn, boxes[total + off[l] + i] = mx;
+    }
   std::vector<float> lut(4 * 256);
   for (int i = 0; i < 256; ++i) {  // photon_mapping.go:105-111
     double angle = (double)i * (1.0 / 256.0) * M_PI;
@@ -247,14 +271,17 @@ static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
   }
   pm->n = n;
   pm->depth = depth;
-  GRT_HIP(hipMalloc(&pm->d_pos4, pos4.size() * sizeof(float4)));
-  GRT_HIP(hipMalloc(&pm->d_pow3, pow3.size() * sizeof(float)));
+  pm->levels = levels;
+  pm->b0 = b0;
+  pm->n_boxes = (int)total;
+  GRT_HIP(hipMalloc(&pm->d_pos3, pos3.size() * sizeof(float)));
+  GRT_HIP(hipMalloc(&pm->d_pwb, pwb.size() * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_lut, lut.size() * sizeof(float)));
-  GRT_HIP(hipMalloc(&pm->d_nodes, nodes.size() * sizeof(float2)));
-  GRT_HIP(hipMemcpy(pm->d_pos4, pos4.data(), pos4.size() * sizeof(float4), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(pm->d_pow3, pow3.data(), pow3.size() * sizeof(float), hipMemcpyHostToDevice));
+  GRT_HIP(hipMalloc(&pm->d_boxes, boxes.size() * sizeof(float4)));
+  GRT_HIP(hipMemcpy(pm->d_pos3, pos3.data(), pos3.size() * sizeof(float), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(pm->d_pwb, pwb.data(), pwb.size() * sizeof(float4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(pm->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(pm->d_nodes, nodes.data(), nodes.size() * sizeof(float2), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(pm->d_boxes, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
   return GRT_OK;
 }
 
@@ -416,16 +443,16 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
   if (!pm) return grt_fail(GRT_EINVAL, "grt_photon_read: NULL map");
   GRT_HIP(hipSetDevice(pm->device));
   const size_t n = (size_t)pm->n;
-  std::vector<float4> p4(n + 1);
-  std::vector<float> w3(3 * (n + 1));
-  GRT_HIP(hipMemcpy(p4.data(), pm->d_pos4, p4.size() * sizeof(float4), hipMemcpyDeviceToHost));
-  GRT_HIP(hipMemcpy(w3.data(), pm->d_pow3, w3.size() * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<float> p3(3 * (n + 1));
+  std::vector<float4> w4(n + 1);
+  GRT_HIP(hipMemcpy(p3.data(), pm->d_pos3, p3.size() * sizeof(float), hipMemcpyDeviceToHost));
+  GRT_HIP(hipMemcpy(w4.data(), pm->d_pwb, w4.size() * sizeof(float4), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) {  // back to storage (emission) order
     const size_t d = (size_t)pm->order[i];
     int bits;
-    memcpy(&bits, &p4[i].w, 4);
-    if (pos) pos[3 * d] = p4[i].x, pos[3 * d + 1] = p4[i].y, pos[3 * d + 2] = p4[i].z;
-    if (power) power[3 * d] = w3[3 * i], power[3 * d + 1] = w3[3 * i + 1], power[3 * d + 2] = w3[3 * i + 2];
+    memcpy(&bits, &w4[i].w, 4);
+    if (pos) pos[3 * d] = p3[3 * i], pos[3 * d + 1] = p3[3 * i + 1], pos[3 * d + 2] = p3[3 * i + 2];
+    if (power) power[3 * d] = w4[i].x, power[3 * d + 1] = w4[i].y, power[3 * d + 2] = w4[i].z;
     if (theta_phi) theta_phi[2 * d] = (uint8_t)(bits >> 8), theta_phi[2 * d + 1] = (uint8_t)(bits >> 16);
   }
   return GRT_OK;
@@ -434,105 +461,217 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
 GRT_API void grt_photon_free(grt_pmap* pm) {
   if (!pm) return;
   if (hipSetDevice(pm->device) == hipSuccess) {
-    (void)hipFree(pm->d_pos4);
-    (void)hipFree(pm->d_pow3);
+    (void)hipFree(pm->d_pos3);
+    (void)hipFree(pm->d_pwb);
     (void)hipFree(pm->d_lut);
-    (void)hipFree(pm->d_nodes);
+    (void)hipFree(pm->d_boxes);
   }
   delete pm;
 }
 
 // ---- k-nearest gather: one wave per query --------------------------------------------------
 // IrradianceEst (photon_mapping.go:125-162).  A WAVE serves one query at a time:
-//   - the walk down the split planes is wave-uniform (node index, stack and bound live in
-//     SGPRs, the stack is two VGPRs indexed by lane: push = v_cndmask on lane == sp, pop = v_readlane); the top
-//     GATHER_TOP_NODES planes are read from an LDS copy, deeper ones by scalar loads;
+//   - the tree walk is wave-uniform: one step tests the (up to) 64 child boxes of a node, one
+//     box per lane (squared distance from the query to the box against the current bound),
+//     and a ballot gives the children to visit; the pending-children masks of the <= 5 levels
+//     are the only stack.  The first GATHER_LDS_BOXES boxes (the top levels) are read from an
+//     LDS copy, deeper ones from HBM/L2 by one coalesced load;
 //   - a leaf bucket is ONE coalesced load: lane l tests photon start+l;
 //   - photons within the current bound are appended to the wave's candidate pool in LDS
-//     (ballot + mbcnt compaction).  NearestSet + NKeeper(k) (photon_mapping.go:131-133) becomes a
-//     selection of the k-th smallest squared distance in the pool: 31 steps of bisection on the
-//     float bits, each step one v_cmp + s_bcnt1 per pool register.  The selection runs when the
-//     pool first holds k photons (the first finite bound), when the pool is full (then the pool
-//     is compacted to the photons within the new bound) and once at the end;
+//     (ballot + mbcnt compaction).  NearestSet + NKeeper(k) (photon_mapping.go:131-133) becomes
+//     the selection of the k-th smallest squared distance in the pool: a 256-bin histogram of
+//     d^2 / max (LDS atomics), a wave prefix sum to find the bin holding the k-th, and an exact
+//     ranking of that bin's few members (bisection on the float bits if the bin is crowded).
+//     The selection runs when the pool first holds k photons without a finite bound, when the
+//     pool is full (then it is compacted to the photons within the new bound) and at the end;
 //   - consecutive queries of a wave are neighbours when the caller passes them in image order,
-//     and the k-th distance is 1-Lipschitz: (r_k(previous) + |q - previous|)^2 is a valid bound
-//     from the first node on, so most queries run exactly one selection;
-//   - the loop of photon_mapping.go:138-161 runs over the pool, one candidate per lane, and a
-//     wave reduction produces the sums.
-// Exact: every photon with d^2 <= (k-th smallest d^2) is accepted, as in the oracle.
-#define GATHER_TOP_NODES 1024
-#define GATHER_WAVES 4
+//     and the k-th distance is 1-Lipschitz: (r_k(previous) + |q - previous|)^2 bounds the
+//     search from the first step on.  A query without a predecessor first walks nearest-child-
+//     first to the nearest leaves and takes the largest distance of k photons found there;
+//   - the loop of photon_mapping.go:138-161 runs over the pool, one candidate per lane, and
+//     DPP wave reductions produce the sums.
+// Exact: every photon with d^2 <= (k-th smallest d^2) is accepted, as in the oracle.  Pruning
+// is safe in floating point: a box distance is computed with the same operation order as a
+// photon distance and rounding is monotone, so box d^2 <= d^2 of every photon inside.
+#define GATHER_LDS_BOXES 320
+#define GATHER_BINS 256
 
-GRT_DEV float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+template <int CTRL, int ROWMASK>
+GRT_DEV int dpp_i(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false);
+}
+// Inclusive scans / totals over the 64 lanes: row_shr 1,2,4,8 inside each row of 16, then
+// row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3.  Lane 63 ends with the total.
+#define GRT_WAVE_SCAN(v, OP, ID)                \
+  v = OP(v, dpp_i<0x111, 0xf>(ID, v));          \
+  v = OP(v, dpp_i<0x112, 0xf>(ID, v));          \
+  v = OP(v, dpp_i<0x114, 0xf>(ID, v));          \
+  v = OP(v, dpp_i<0x118, 0xf>(ID, v));          \
+  v = OP(v, dpp_i<0x142, 0xa>(ID, v));          \
+  v = OP(v, dpp_i<0x143, 0xc>(ID, v));
+GRT_DEV int op_add_i(int a, int b) { return a + b; }
+GRT_DEV int op_add_f(int a, int b) { return __float_as_int(__int_as_float(a) + __int_as_float(b)); }
+GRT_DEV int op_max_u(int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); }
+GRT_DEV int op_min_u(int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); }
+GRT_DEV int wave_scan_add_i(int v) {
+  GRT_WAVE_SCAN(v, op_add_i, 0)
   return v;
 }
-GRT_DEV float wave_max_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+GRT_DEV int wave_total_add_i(int v) {
+  GRT_WAVE_SCAN(v, op_add_i, 0)
+  return __builtin_amdgcn_readlane(v, 63);
 }
-GRT_DEV int wave_sum_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+GRT_DEV float wave_total_add_f(float f) {
+  int v = __float_as_int(f);
+  GRT_WAVE_SCAN(v, op_add_f, 0)
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+GRT_DEV uint32_t wave_total_max_u(uint32_t u) {
+  int v = (int)u;
+  GRT_WAVE_SCAN(v, op_max_u, 0)
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+GRT_DEV uint32_t wave_total_min_u(uint32_t u) {
+  int v = (int)u;
+  GRT_WAVE_SCAN(v, op_min_u, -1)
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 GRT_DEV int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-GRT_DEV float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-GRT_DEV bool uniform_true(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+GRT_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+GRT_DEV int mbcnt64(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
 
+struct P3 {
+  float x, y, z;
+};
 struct KdView {
-  const float2* __restrict__ nodes;
-  const float4* __restrict__ pos4;
-  const float* __restrict__ pow3;
+  const float4* __restrict__ boxes;
+  const float* __restrict__ pos3;
+  const float4* __restrict__ pwb;
   const float* __restrict__ lut;
-  int n, depth;
+  int n, depth, levels, b0, n_boxes;
 };
 
-// k-th smallest (1-based) of the pool's squared distances, as float bits.  v[r] holds the bits
-// of entry lane + 64 r (0xffffffff beyond the pool).  Squared distances are non-negative, so
-// their bit patterns order like unsigned integers.
+// k-th smallest (1-based) of the values v[r] (float bits of non-negative numbers, which order
+// like unsigned integers; 0xffffffff = no entry) by bisection on the bits.
 template <int RMAX>
-GRT_DEV uint32_t select_kth(const uint32_t (&v)[RMAX], int k) {
+GRT_DEV uint32_t select_kth_bits(const uint32_t (&v)[RMAX], int k) {
   uint32_t T = 0;
 #pragma unroll 1
   for (int bit = 30; bit >= 0; --bit) {
     const uint32_t cand = T | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[r] < cand));
+    for (int r = 0; r < RMAX; ++r) c += popc64(__builtin_amdgcn_ballot_w64(v[r] < cand));
     if (c < k) T = cand;
   }
   return T;
 }
 
+// The same through a histogram.  v[r] = entry lane + 64 r of a pool of `count` >= k entries.
 template <int RMAX>
-__global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather_knn(KdView T, const float* __restrict__ qpos,
+GRT_DEV uint32_t select_kth(const uint32_t (&v)[RMAX], int count, int k, int lane, int* hist) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) m = max(m, v[r] == 0xffffffffu ? 0u : v[r]);
+  const uint32_t bmax = wave_total_max_u(m);
+  if (bmax == 0u) return 0u;  // every distance is zero
+  const float scale = 255.5f * rcp32(__uint_as_float(bmax));
+  int key[RMAX];
+  *(int4*)(hist + 4 * lane) = make_int4(0, 0, 0, 0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    key[r] = -1;
+    if (64 * r < count) {  // wave-uniform
+      if (v[r] != 0xffffffffu) {
+        key[r] = min(GATHER_BINS - 1, (int)(__uint_as_float(v[r]) * scale));  // monotone in the value
+        atomicAdd(hist + key[r], 1);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int4 h = *(const int4*)(hist + 4 * lane);
+  const int s = h.x + h.y + h.z + h.w;
+  const int inc = wave_scan_add_i(s);
+  const int L = __builtin_ctzll(__builtin_amdgcn_ballot_w64(inc >= k));  // lane whose 4 bins hold the k-th
+  const int excl = inc - s, c1 = excl + h.x, c2 = c1 + h.y, c3 = c2 + h.z;
+  const int bl = c1 >= k ? 0 : (c2 >= k ? 1 : (c3 >= k ? 2 : 3));
+  const int below_l = bl == 0 ? excl : (bl == 1 ? c1 : (bl == 2 ? c2 : c3));
+  const int b = __builtin_amdgcn_readlane(4 * lane + bl, L);
+  const int j = k - __builtin_amdgcn_readlane(below_l, L);  // 1-based rank inside bin b
+  uint32_t mv[RMAX];
+  int members = 0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    mv[r] = key[r] == b ? v[r] : 0xffffffffu;
+    members += popc64(__builtin_amdgcn_ballot_w64(key[r] == b));
+  }
+  if (members == 1) {  // the usual case: the k-th is alone in its bin
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(key[r] == b);
+      if (mk) return (uint32_t)__builtin_amdgcn_readlane((int)v[r], __builtin_ctzll(mk));
+    }
+  }
+  if (members <= 8) {  // rank the members one at a time
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      unsigned long long mk = __builtin_amdgcn_ballot_w64(key[r] == b);
+      while (mk) {
+        const int l = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v[r], l);
+        int less = 0, leq = 0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+          less += popc64(__builtin_amdgcn_ballot_w64(mv[q] < x));
+          leq += popc64(__builtin_amdgcn_ballot_w64(mv[q] <= x));
+        }
+        if (less < j && j <= leq) return x;
+      }
+    }
+  }
+  return select_kth_bits<RMAX>(mv, j);
+}
+
+template <int RMAX, int GATHER_WAVES>
+__global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(80))) void k_gather_knn(KdView T, const float* __restrict__ qpos,
                                                                   const float* __restrict__ qnrm, int n_q, int q_per_wave,
                                                                   float radius, int k, float* __restrict__ irrad,
-                                                                  float* __restrict__ rk2_out) {
+                                                                  float* __restrict__ rk2_out,
+                                                                  unsigned long long* __restrict__ stats) {
   constexpr int CAP = 64 * RMAX;
-  __shared__ float2 top[GATHER_TOP_NODES];
+  __shared__ float4 top_lo[GATHER_LDS_BOXES], top_hi[GATHER_LDS_BOXES];
   __shared__ float pool_d2[GATHER_WAVES][CAP];
   __shared__ int pool_ix[GATHER_WAVES][CAP];
-  const int leaf_base = 1 << T.depth;
-  const int lds_end = min(leaf_base, GATHER_TOP_NODES);
-  for (int i = threadIdx.x; i < GATHER_TOP_NODES; i += blockDim.x) top[i] = i < leaf_base ? T.nodes[i] : make_float2(0.0f, 0.0f);
+  __shared__ __attribute__((aligned(16))) int hist_all[GATHER_WAVES][GATHER_BINS];
+  __shared__ float lut[4 * 256];  // costheta, sintheta, cosphi, sinphi (photon_mapping.go:90-93)
+  for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = T.lut[i];
+  for (int i = threadIdx.x; i < min(GATHER_LDS_BOXES, T.n_boxes); i += blockDim.x) {
+    top_lo[i] = T.boxes[i];
+    top_hi[i] = T.boxes[T.n_boxes + i];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = sgpr(threadIdx.x >> 6);
   float* pd2 = pool_d2[wave];
   int* pix = pool_ix[wave];
+  int* hist = hist_all[wave];
   const int q0 = (blockIdx.x * GATHER_WAVES + wave) * q_per_wave;
   const int q1 = min(q0 + q_per_wave, n_q);
   const float radius2 = radius * radius;
+  const int last = T.levels - 1;
   float prev_rk = -1.0f, pqx = 0.0f, pqy = 0.0f, pqz = 0.0f;  // k-th distance of the previous query (if it had one)
 
+  float nqx = 0.0f, nqy = 0.0f, nqz = 0.0f;  // the next query's position is requested one query ahead
+  if (q0 < q1) nqx = qpos[3 * (size_t)q0], nqy = qpos[3 * (size_t)q0 + 1], nqz = qpos[3 * (size_t)q0 + 2];
   for (int qi = q0; qi < q1; ++qi) {
-    const float qx = qpos[3 * (size_t)qi], qy = qpos[3 * (size_t)qi + 1], qz = qpos[3 * (size_t)qi + 2];
+    const float qx = nqx, qy = nqy, qz = nqz;
+    if (qi + 1 < q1) nqx = qpos[3 * (size_t)qi + 3], nqy = qpos[3 * (size_t)qi + 4], nqz = qpos[3 * (size_t)qi + 5];
     float bound = radius > 0.0f ? radius2 : INFINITY;  // photons beyond the radius never count (:141)
-    bool tight = false;                                // bound comes from k photons already seen
+    bool tight = false;                                // the bound encloses k photons
     if (prev_rk >= 0.0f) {
       const float dx = qx - pqx, dy = qy - pqy, dz = qz - pqz;
       const float r = prev_rk + sqrt32(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
@@ -541,16 +680,56 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather_knn(KdView T, cons
     }
     int count = 0;
     uint32_t vb[RMAX];
+    int st_nodes = 0, st_leaves = 0, st_sel = 0;  // tuning counters (stats != NULL only)
 
-    // refresh the bound from the pool; compact the pool when it is full
-    auto reselect = [&](bool compact) {
+    // one step of the walk: the children of node `prefix` at level lvl (boxes off .. ), one per lane
+    auto test_group = [&](int lvl, int off, int prefix, float bnd, float& d2box) -> unsigned long long {
+      const int nb = lvl == 0 ? T.b0 : KD_FAN_BITS;
+      const int base = off + (prefix << nb);
+      const bool act = lane < (1 << nb);
+      const int rec = base + (act ? lane : 0);
+      float4 lo, hi;
+      if (base + 64 <= GATHER_LDS_BOXES) lo = top_lo[rec], hi = top_hi[rec];
+      else lo = T.boxes[rec], hi = T.boxes[T.n_boxes + rec];
+      const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.0f);
+      const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.0f);
+      const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.0f);
+      d2box = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      st_nodes++;
+      return __builtin_amdgcn_ballot_w64(act & (d2box <= bnd));
+    };
+    // one leaf bucket: photons within bnd go to the pool
+    auto append_leaf = [&](int leaf, float bnd) {
+      const int a = (int)(((long long)leaf * (long long)T.n) >> T.depth);
+      const int b = (int)(((long long)(leaf + 1) * (long long)T.n) >> T.depth);
+      const int i = a + lane;
+      const bool valid = i < b;
+      const P3 p = *(const P3*)(T.pos3 + 3 * (size_t)(valid ? i : a));  // one 12-byte load per lane
+      const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+      const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      const bool pass = valid & (d2 <= bnd);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+      const int slot = count + mbcnt64(m);
+      if (pass) {
+        pd2[slot] = d2;
+        pix[slot] = i;
+      }
+      count += popc64(m);
+      st_leaves++;
+    };
+    auto load_pool = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
         const int j = lane + 64 * r;
         vb[r] = j < count ? __float_as_uint(pd2[j]) : 0xffffffffu;
       }
-      const uint32_t Tk = select_kth<RMAX>(vb, k);
+    };
+    // refresh the bound from the pool; compact the pool when it is full
+    auto reselect = [&](bool compact) {
+      st_sel++;
+      load_pool();
+      const uint32_t Tk = select_kth<RMAX>(vb, count, k, lane, hist);
       bound = __uint_as_float(Tk);
       tight = true;
       if (compact) {
@@ -561,122 +740,141 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather_knn(KdView T, cons
           const bool keep = vb[r] <= Tk;
           const int ix = pix[j];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-          const int slot = nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+          const int slot = nc + mbcnt64(m);
           if (keep) {
             pd2[slot] = __uint_as_float(vb[r]);
             pix[slot] = ix;
           }
-          nc += __builtin_popcountll(m);
+          nc += popc64(m);
         }
         count = nc;
       }
     };
 
     if (T.n > 0) {
-      // wave-uniform walk: near child first, far child pushed with its plane distance
-      int stk_node = 0;
-      float stk_d2 = 0.0f;
-      int sp = 0, node = 1;
-      for (;;) {
-        // descend: the index only grows, so the LDS-resident levels come first
-#define GRT_KD_STEP(ND)                                                                   \
-  {                                                                                       \
-    const float2 nd = (ND);                                                               \
-    const int ax = sgpr(__float_as_int(nd.y));                                            \
-    const float qa = ax == 0 ? qx : (ax == 1 ? qy : qz);                                  \
-    const float delta = qa - nd.x;                                                        \
-    const int right = sgpr(__float_as_int(delta)) >= 0 ? 1 : 0;                           \
-    const float dd = delta * delta;                                                       \
-    if (uniform_true(dd <= bound)) {                                                      \
-      const bool top_lane = lane == sp; /* lane sp of the two stack registers */          \
-      stk_node = top_lane ? 2 * node + (right ^ 1) : stk_node;                            \
-      stk_d2 = top_lane ? dd : stk_d2;                                                    \
-      sp++;                                                                               \
-    }                                                                                     \
-    node = 2 * node + right;                                                              \
-  }
-        while (node < lds_end) GRT_KD_STEP(top[node]);
-        while (node < leaf_base) GRT_KD_STEP(T.nodes[node]);
-#undef GRT_KD_STEP
-        {  // leaf bucket: one photon per lane
-          const int leaf = node - leaf_base;
-          const int a = (int)(((long long)leaf * (long long)T.n) >> T.depth);
-          const int b = (int)(((long long)(leaf + 1) * (long long)T.n) >> T.depth);
-          const int i = a + lane;
-          const bool valid = i < b;
-          const float4 p = T.pos4[valid ? i : a];
-          const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          const bool pass = valid & (d2 <= bound);
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-          if (m) {
-            const int slot = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (pass) {
-              pd2[slot] = d2;
-              pix[slot] = i;
+      if (!tight && radius == 0.0f) {
+        // No bound yet: nearest child first down to the nearest leaves until k photons are seen;
+        // their largest distance bounds the k-th.  The pool is then emptied and the walk below
+        // starts over with that bound.
+        int off = 0, nl = 1 << T.b0, prefix = 0;
+        for (int lvl = 0; lvl <= last; ++lvl) {
+          float d2box;
+          unsigned long long rem = test_group(lvl, off, prefix, bound, d2box);
+          const int nb = lvl == 0 ? T.b0 : KD_FAN_BITS;
+          if (rem == 0ull) break;  // nothing within the radius
+          while (rem) {
+            const bool in = (rem >> lane) & 1ull;
+            const uint32_t dmin = wave_total_min_u(in ? __float_as_uint(d2box) : 0xffffffffu);
+            const int l = __builtin_ctzll(__builtin_amdgcn_ballot_w64(in & (__float_as_uint(d2box) == dmin)));
+            rem &= ~(1ull << l);
+            if (lvl < last) {
+              prefix = (prefix << nb) | l;
+              break;
             }
-            count += __builtin_popcountll(m);
+            append_leaf((prefix << nb) | l, bound);
+            if (count >= k) break;
+          }
+          off += nl;
+          nl <<= KD_FAN_BITS;
+        }
+        if (count >= k) {
+          load_pool();
+          uint32_t m = 0;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) m = max(m, vb[r] == 0xffffffffu ? 0u : vb[r]);
+          bound = __uint_as_float(wave_total_max_u(m));
+          tight = true;
+        }
+        count = 0;
+      }
+
+      // depth-first walk over the boxes within the bound
+      int stk_lo = 0, stk_hi = 0;  // pending-children masks, level l in lane l
+      int lvl = 0, off = 0, nl = 1 << T.b0, prefix = 0;
+      float d2box;
+      unsigned long long mask = test_group(0, 0, 0, bound, d2box);
+      for (;;) {
+        if (lvl == last) {  // the children are leaf buckets
+          const int pb = prefix << (lvl == 0 ? T.b0 : KD_FAN_BITS);
+          while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            append_leaf(pb | l, bound);
             if (count > CAP - 64) reselect(true);
             else if (!tight && count >= k) reselect(false);
           }
         }
-        bool more = false;
-        while (sp > 0) {  // next far subtree still within the bound
-          sp--;
-          const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(stk_d2), sp));
-          if (uniform_true(d <= bound)) {
-            node = __builtin_amdgcn_readlane(stk_node, sp);
-            more = true;
-            break;
-          }
+        if (mask == 0ull) {  // back to the parent's pending children
+          if (lvl == 0) break;
+          lvl--;
+          nl >>= KD_FAN_BITS;
+          off -= nl;
+          prefix >>= (lvl == 0 ? T.b0 : KD_FAN_BITS);
+          mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(stk_hi, lvl) << 32) |
+                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(stk_lo, lvl);
+          continue;
         }
-        if (!more) break;
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const bool me = lane == lvl;
+        stk_lo = me ? (int)(uint32_t)mask : stk_lo;
+        stk_hi = me ? (int)(uint32_t)(mask >> 32) : stk_hi;
+        prefix = (prefix << (lvl == 0 ? T.b0 : KD_FAN_BITS)) | l;
+        off += nl;
+        nl <<= KD_FAN_BITS;
+        lvl++;
+        mask = test_group(lvl, off, prefix, bound, d2box);
       }
     }
 
     // final selection, then the loop of photon_mapping.go:138-161 over the pool
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int j = lane + 64 * r;
-      vb[r] = j < count ? __float_as_uint(pd2[j]) : 0xffffffffu;
-    }
+    load_pool();
     uint32_t Tk = 0x7f800000u;  // fewer than k photons: all of them
-    if (count >= k) Tk = select_kth<RMAX>(vb, k);
+    if (count >= k) Tk = select_kth<RMAX>(vb, count, k, lane, hist);
     const float nx = qnrm[3 * (size_t)qi], ny = qnrm[3 * (size_t)qi + 1], nz = qnrm[3 * (size_t)qi + 2];
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, r2 = 0.0f;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    uint32_t r2 = 0u;
     int found = 0;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const int j = lane + 64 * r;
-      if (64 * r >= count) break;  // wave-uniform
-      const float d2 = __uint_as_float(vb[r]);
-      if (j < count && vb[r] <= Tk && (radius == 0.0f || d2 < radius2)) {  // :141
-        const int ix = pix[j];
-        const int bits = __float_as_int(T.pos4[ix].w);
-        const int th = (bits >> 8) & 255, ph = (bits >> 16) & 255;
-        const float st = T.lut[256 + th];
-        const float dx = st * T.lut[512 + ph], dy = st * T.lut[768 + ph], dz = T.lut[th];  // PhotonDir, :117-122
-        if (dx * nx + dy * ny + dz * nz < 0.0f) {                                       // :144
-          sx += T.pow3[3 * (size_t)ix], sy += T.pow3[3 * (size_t)ix + 1], sz += T.pow3[3 * (size_t)ix + 2];
-          r2 = fmaxf(r2, d2);
-          found++;
+      if (64 * r < count) {  // wave-uniform
+        const float d2 = __uint_as_float(vb[r]);
+        bool acc = false;
+        if (j < count && vb[r] <= Tk && (radius == 0.0f || d2 < radius2)) {  // :141
+          const float4 pw = T.pwb[pix[j]];
+          const int bits = __float_as_int(pw.w);
+          const int th = (bits >> 8) & 255, ph = (bits >> 16) & 255;
+          const float st = lut[256 + th];
+          const float dx = st * lut[512 + ph], dy = st * lut[768 + ph], dz = lut[th];  // PhotonDir, :117-122
+          if (dx * nx + dy * ny + dz * nz < 0.0f) {                                   // :144
+            sx += pw.x, sy += pw.y, sz += pw.z;
+            r2 = max(r2, vb[r]);
+            acc = true;
+          }
         }
+        found += popc64(__builtin_amdgcn_ballot_w64(acc));
       }
     }
-    sx = wave_sum_f(sx), sy = wave_sum_f(sy), sz = wave_sum_f(sz);
-    r2 = wave_max_f(r2);
-    found = wave_sum_i(found);
-    if (found >= 8) {  // :154-161
-      const float tmp = 1.0f / (PI_F * r2);
-      sx *= tmp, sy *= tmp, sz *= tmp;
+    if (found > 0) {  // wave-uniform
+      sx = wave_total_add_f(sx), sy = wave_total_add_f(sy), sz = wave_total_add_f(sz);
+      if (found >= 8) {  // :154-161
+        const float tmp = rcp32(PI_F * __uint_as_float(wave_total_max_u(r2)));
+        sx *= tmp, sy *= tmp, sz *= tmp;
+      }
+    }
+    if (stats && lane == 0) {
+      atomicAdd(stats + 0, (unsigned long long)st_nodes);
+      atomicAdd(stats + 1, (unsigned long long)st_leaves);
+      atomicAdd(stats + 2, (unsigned long long)st_sel + (count >= k ? 1 : 0));
+      atomicAdd(stats + 3, (unsigned long long)count);
     }
     if (lane == 0) {
       irrad[3 * (size_t)qi] = sx, irrad[3 * (size_t)qi + 1] = sy, irrad[3 * (size_t)qi + 2] = sz;
       if (rk2_out) rk2_out[qi] = count >= k ? __uint_as_float(Tk) : (count ? INFINITY : -1.0f);
     }
     // The bound handed to the next query must be the true k-th distance over ALL photons: it is
-    // when the selection saw k photons and was not cut short by the radius.
+    // when the selection saw k photons (a radius cut leaves fewer than k in the pool otherwise).
     if (count >= k) prev_rk = sqrt32(__uint_as_float(Tk)) * 1.00001f, pqx = qx, pqy = qy, pqz = qz;
     else prev_rk = -1.0f;
   }
@@ -697,15 +895,35 @@ static int gather_qpw() {
 static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
                          float* d_rk2, hipStream_t st) {
   const int qpw = gather_qpw();
-  const unsigned grid = (unsigned)((n + GATHER_WAVES * qpw - 1) / (GATHER_WAVES * qpw));
-  KdView T = {pm->d_nodes, pm->d_pos4, pm->d_pow3, pm->d_lut, pm->n, pm->depth};
-  if (k <= 128)
-    hipLaunchKernelGGL(k_gather_knn<5>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
-  else if (k <= 256)
-    hipLaunchKernelGGL(k_gather_knn<9>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
-  else
-    hipLaunchKernelGGL(k_gather_knn<17>, dim3(grid), dim3(64 * GATHER_WAVES), 0, st, T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2);
+  KdView T = {pm->d_boxes, pm->d_pos3, pm->d_pwb, pm->d_lut, pm->n, pm->depth, pm->levels, pm->b0, pm->n_boxes};
+  // GRT_GATHER_STATS=1 (tuning runs only): per-launch totals of node steps, leaf buckets read,
+  // selections and pool sizes on stderr; allocates and synchronises, so never set in production.
+  unsigned long long* d_stats = nullptr;
+  if (getenv("GRT_GATHER_STATS")) {
+    GRT_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
+    GRT_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), st));
+  }
+  // waves per workgroup by pool size, so that the LDS pools of a CU's 32 waves fit in 160 KB
+#define GRT_GATHER_LAUNCH(RMAX, WAVES)                                                                               \
+  hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, \
+                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats)
+  const char* wenv = getenv("GRT_GATHER_WAVES");  // tuning: waves per workgroup of the k <= 128 kernel
+  const int wsel = wenv ? atoi(wenv) : 16;
+  if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4);
+  else if (k <= 128 && wsel == 8) GRT_GATHER_LAUNCH(5, 8);
+  else if (k <= 128) GRT_GATHER_LAUNCH(5, 16);
+  else if (k <= 256) GRT_GATHER_LAUNCH(9, 8);
+  else GRT_GATHER_LAUNCH(17, 4);
+#undef GRT_GATHER_LAUNCH
   GRT_HIP(hipGetLastError());
+  if (d_stats) {
+    unsigned long long h[4];
+    GRT_HIP(hipStreamSynchronize(st));
+    GRT_HIP(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d_stats);
+    fprintf(stderr, "[gather stats] n=%d k=%d radius=%g qpw=%d: node steps %.1f, leaf buckets %.2f, selections %.2f, pool %.1f per query\n",
+            n, k, (double)radius, qpw, (double)h[0] / n, (double)h[1] / n, (double)h[2] / n, (double)h[3] / n);
+  }
   return GRT_OK;
 }
 

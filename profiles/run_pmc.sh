@@ -1,17 +1,24 @@
 #!/bin/bash
-# PMC passes for the C3 bench (run on the GPU box from the repo root):  bash profiles/run_pmc.sh <outdir>
-# One rocprofv3 run per counter set (the tool does not split passes); --pmc never combined with traces.
+# PMC passes for one command (run on the GPU box from the repo root):
+#   bash profiles/run_pmc.sh <outdir> <script.py> [args...]
+# One rocprofv3 run per counter set (the tool does not split passes); --pmc is never combined
+# with traces.  python3 is the profiled program itself (no env/bash hop after `--`).
 set -u
-OUT=${1:-gpurun_out/pmc}
+OUT=$1; shift
+SCRIPT=$1; shift
 mkdir -p "$OUT"
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline > "$ROOT/$OUT/$name.log" 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/$SCRIPT" "${ARGS[@]}" > "$ROOT/$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
+ARGS=("$@")
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES || exit 1
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_LDS || exit 1
+run sq3 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD || exit 1
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
 run write WRITE_SIZE GRBM_COUNT || exit 1
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
+cd "$ROOT" && python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.json" && cat "$OUT/summary.json"
