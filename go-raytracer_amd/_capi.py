@@ -18,6 +18,8 @@ GRT_KIND_AABB = 1
 GRT_JITTER_CENTER = 0
 GRT_JITTER_RNG = 1
 GRT_BAND_ROWS = 8
+GRT_ACCEL_AUTO = 0
+GRT_ACCEL_BVH = 1
 
 
 class Camera(C.Structure):
@@ -39,7 +41,7 @@ class PrimRec(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
-                ("_pad", C.c_int32), ("bias", C.c_double), ("cam", Camera)]
+                ("accel", C.c_int32), ("bias", C.c_double), ("cam", Camera)]
 
 
 class Opts(C.Structure):
@@ -63,6 +65,7 @@ PROTOTYPES = {
     "grt_render_accum": (C.c_int, [_vp, P(Opts), _vp, C.c_int32]),
     "grt_render_accum_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32, _vp, _vp,
                                        C.c_uint64, _vp, _vp]),
+    "grt_render_accum_samples_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, _vp, _vp, C.c_uint64, _vp, _vp]),
     "grt_shard_rows": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "grt_accum_workspace_bytes": (C.c_uint64, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32]),
     "grt_tonemap_dev": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),

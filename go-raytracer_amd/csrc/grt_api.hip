@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <future>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,9 +56,9 @@ static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_
   if ((int64_t)d->width * d->height > (int64_t)1 << 28) return grt_fail(GRT_ELIMIT, "grt_scene_create: image above 2^28 pixels");
   if (n_prims < 0 || n_mats < 0 || (n_prims && !prims) || (n_mats && !mats))
     return grt_fail(GRT_EINVAL, "grt_scene_create: bad prim/material arrays");
-  if (n_prims > GRT_MAX_LINEAR_PRIMS)
-    return grt_fail(GRT_ELIMIT, "grt_scene_create: %d objects; the linear-scan kernels take at most %d", n_prims,
-                    GRT_MAX_LINEAR_PRIMS);
+  if (n_prims > GRT_MAX_PRIMS) return grt_fail(GRT_ELIMIT, "grt_scene_create: %d objects; at most %d", n_prims, GRT_MAX_PRIMS);
+  if (d->accel != GRT_ACCEL_AUTO && d->accel != GRT_ACCEL_BVH)
+    return grt_fail(GRT_EINVAL, "grt_scene_create: unknown accel %d", d->accel);
   for (int i = 0; i < n_prims; ++i) {
     if (prims[i].kind != GRT_KIND_SPHERE && prims[i].kind != GRT_KIND_AABB)
       return grt_fail(GRT_EINVAL, "grt_scene_create: object %d has unknown kind %d", i, prims[i].kind);
@@ -71,8 +73,19 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   if (!out) return grt_fail(GRT_EINVAL, "grt_scene_create: out is NULL");
   int rc = validate_scene(desc, prims, n_prims, mats, n_mats);
   if (rc) return rc;
+  const bool use_bvh = n_prims > GRT_MAX_LINEAR_PRIMS || (desc->accel == GRT_ACCEL_BVH && n_prims > 0);
+  if (use_bvh)
+    for (int i = 0; i < n_prims; ++i) {
+      const grt_material& m = mats[prims[i].material];
+      // The direct-light branch of trace() (scene.go:322-346) walks every object in index order
+      // with a shrinking tNear: it has no order-free form, so it stays with the linear scan.
+      if (!m.normal && !(m.emittance > 0) && !m.lambert && !(m.reflectivity > 0) && !m.transparent)
+        return grt_fail(GRT_ELIMIT, "grt_scene_create: object %d has a plain DiffuseMaterial (material.go:20); its shadow loop "
+                        "(scene.go:336-344) needs the linear scan, which takes at most %d objects", i, GRT_MAX_LINEAR_PRIMS);
+    }
   grt_scene* s = new grt_scene;
   s->d = *desc;
+  s->use_bvh = use_bvh;
   s->prims.assign(prims, prims + n_prims);
   s->mats.assign(mats, mats + n_mats);
   for (int i = 0; i < n_prims; ++i) {  // NewScene, scene.go:40-51
@@ -97,12 +110,122 @@ GRT_API void grt_scene_destroy(grt_scene* s) {
     (void)hipFree(kv.second.mats);
     (void)hipFree(kv.second.lights);
     (void)hipFree(kv.second.prims64);
+    (void)hipFree(kv.second.bvh_nodes);
+    (void)hipFree(kv.second.bvh_prims);
+    (void)hipFree(kv.second.bvh_ids);
   }
   if (have) (void)hipSetDevice(cur);
   delete s;
 }
 
 const grt_scene_desc* grt_scene_desc_of(const grt_scene* s) { return &s->d; }
+
+// ---- bounding-volume hierarchy (grt_bvh.h) ----------------------------------------------
+// Median split on the axis of largest centroid extent down to leaves of <= GRT_BVH_LEAF
+// objects: balanced, so the traversal stack depth is log2(n / leaf) + 1 (checked against
+// GRT_BVH_STACK).  Built on the host from the FP32 records the kernels test.
+struct BvhBuild {
+  const std::vector<float4>* hp;   // the staged object records (2 per object)
+  std::vector<float> lo, hi;       // padded object boxes, 3 per object
+  std::vector<int> order;          // slot -> object index
+  std::vector<float4> nodes;
+  std::atomic<int> n_nodes{0};
+  int max_depth = 0;
+  std::mutex mu;
+};
+static void bvh_range_box(const BvhBuild& B, int a, int b, float* lo, float* hi) {
+  for (int c = 0; c < 3; ++c) lo[c] = 3e38f, hi[c] = -3e38f;
+  for (int i = a; i < b; ++i)
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = std::min(lo[c], B.lo[3 * (size_t)B.order[i] + c]);
+      hi[c] = std::max(hi[c], B.hi[3 * (size_t)B.order[i] + c]);
+    }
+}
+// Returns the reference of the subtree over order[a, b) and its box.
+static int bvh_build(BvhBuild& B, int a, int b, float* lo, float* hi, int depth, int par_depth) {
+  bvh_range_box(B, a, b, lo, hi);
+  if (b - a <= GRT_BVH_LEAF) {
+    std::lock_guard<std::mutex> g(B.mu);
+    B.max_depth = std::max(B.max_depth, depth);
+    return ~((a << 3) | (b - a));
+  }
+  float cl[3] = {3e38f, 3e38f, 3e38f}, ch[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = a; i < b; ++i)
+    for (int c = 0; c < 3; ++c) {
+      const float m = 0.5f * (B.lo[3 * (size_t)B.order[i] + c] + B.hi[3 * (size_t)B.order[i] + c]);
+      cl[c] = std::min(cl[c], m), ch[c] = std::max(ch[c], m);
+    }
+  int ax = 0;
+  if (ch[1] - cl[1] > ch[ax] - cl[ax]) ax = 1;
+  if (ch[2] - cl[2] > ch[ax] - cl[ax]) ax = 2;
+  const int mid = a + (b - a) / 2;
+  std::nth_element(B.order.begin() + a, B.order.begin() + mid, B.order.begin() + b, [&](int x, int y) {
+    const float cx = B.lo[3 * (size_t)x + ax] + B.hi[3 * (size_t)x + ax], cy = B.lo[3 * (size_t)y + ax] + B.hi[3 * (size_t)y + ax];
+    return cx < cy || (cx == cy && x < y);
+  });
+  const int me = B.n_nodes.fetch_add(1);
+  float l0[3], h0[3], l1[3], h1[3];
+  int r0, r1;
+  if (par_depth > 0 && b - a > 16384) {
+    auto fut = std::async(std::launch::async, [&] { return bvh_build(B, a, mid, l0, h0, depth + 1, par_depth - 1); });
+    r1 = bvh_build(B, mid, b, l1, h1, depth + 1, par_depth - 1);
+    r0 = fut.get();
+  } else {
+    r0 = bvh_build(B, a, mid, l0, h0, depth + 1, 0);
+    r1 = bvh_build(B, mid, b, l1, h1, depth + 1, 0);
+  }
+  float4* n = &B.nodes[4 * (size_t)me];
+  n[0] = make_float4(l0[0], l0[1], l0[2], __builtin_bit_cast(float, r0));
+  n[1] = make_float4(h0[0], h0[1], h0[2], 0.0f);
+  n[2] = make_float4(l1[0], l1[1], l1[2], __builtin_bit_cast(float, r1));
+  n[3] = make_float4(h1[0], h1[1], h1[2], 0.0f);
+  return me;
+}
+
+static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceScene& d) {
+  const int n = (int)s->prims.size();
+  BvhBuild B;
+  B.hp = &hp;
+  B.lo.resize(3 * (size_t)n), B.hi.resize(3 * (size_t)n), B.order.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const float4 pa = hp[2 * (size_t)i], pb = hp[2 * (size_t)i + 1];
+    const bool box = (__builtin_bit_cast(int, pb.w) & 1) != 0;
+    const float c[3] = {pa.x, pa.y, pa.z}, e[3] = {pb.x, pb.y, pb.z};
+    for (int k = 0; k < 3; ++k) {
+      float l = box ? std::min(c[k], e[k]) : c[k] - std::fabs(pa.w);
+      float h = box ? std::max(c[k], e[k]) : c[k] + std::fabs(pa.w);
+      // padding: the slab arithmetic of a box around a sphere and sphere_hit32 round differently
+      const float pad = 4e-6f * (std::fabs(l) + std::fabs(h) + (h - l)) + 1e-30f;
+      B.lo[3 * (size_t)i + k] = l - pad, B.hi[3 * (size_t)i + k] = h + pad;
+    }
+    B.order[i] = i;
+  }
+  B.nodes.resize(4 * (size_t)std::max(1, n));
+  float lo[3], hi[3];
+  if (n <= GRT_BVH_LEAF) {  // a single leaf still needs a root node: the second child is empty
+    bvh_range_box(B, 0, n, lo, hi);
+    B.n_nodes = 1;
+    B.nodes[0] = make_float4(lo[0], lo[1], lo[2], __builtin_bit_cast(float, ~((0 << 3) | n)));
+    B.nodes[1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    B.nodes[2] = make_float4(3e38f, 3e38f, 3e38f, __builtin_bit_cast(float, ~0));
+    B.nodes[3] = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);
+  } else {
+    const int root = bvh_build(B, 0, n, lo, hi, 0, 4);
+    if (root != 0) return grt_fail(GRT_EINVAL, "internal: BVH root is node %d", root);
+    if (B.max_depth + 1 > GRT_BVH_STACK)
+      return grt_fail(GRT_ELIMIT, "grt_scene: hierarchy depth %d exceeds the traversal stack (%d)", B.max_depth, GRT_BVH_STACK);
+  }
+  std::vector<float4> bp(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) bp[2 * (size_t)i] = hp[2 * (size_t)B.order[i]], bp[2 * (size_t)i + 1] = hp[2 * (size_t)B.order[i] + 1];
+  const size_t nn = 4 * (size_t)B.n_nodes.load();
+  GRT_HIP(hipMalloc(&d.bvh_nodes, nn * sizeof(float4)));
+  GRT_HIP(hipMalloc(&d.bvh_prims, bp.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&d.bvh_ids, (size_t)n * sizeof(int)));
+  GRT_HIP(hipMemcpy(d.bvh_nodes, B.nodes.data(), nn * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.bvh_prims, bp.data(), bp.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.bvh_ids, B.order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  return GRT_OK;
+}
 
 // Stage the SoA copies on the current device (first use only).
 static int stage(grt_scene* s, DeviceScene& out) {
@@ -163,6 +286,10 @@ static int stage(grt_scene* s, DeviceScene& out) {
   GRT_HIP(hipMemcpy(d.mats, hm.data(), hm.size() * sizeof(float4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(d.lights, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(d.prims64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (s->use_bvh) {
+    int rc = stage_bvh(s, hp, d);
+    if (rc) return rc;
+  }
   s->dev[dev] = d;
   out = d;
   return GRT_OK;
@@ -188,6 +315,7 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
   for (size_t i = 0; i < s->prims.size() && i < 32; ++i)
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
+  k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_ids = d.bvh_ids;
   *ks = k;
   return GRT_OK;
 }
@@ -211,7 +339,7 @@ static int kernel_view64(grt_scene* s, KScene64* k64) {
 // Scenes of up to GRT_FAST_PRIMS objects (the reference's own scene has 8, main.go:40-49) run
 // the kernel instance that keeps the objects in registers; larger ones read them from HBM.
 static bool scene_is_small(const grt_scene* s) {
-  return (int)s->prims.size() <= GRT_FAST_PRIMS && (int)s->mats.size() <= GRT_FAST_PRIMS && !getenv("GRT_FORCE_GENERIC");
+  return !s->use_bvh && (int)s->prims.size() <= GRT_FAST_PRIMS && (int)s->mats.size() <= GRT_FAST_PRIMS && !getenv("GRT_FORCE_GENERIC");
 }
 
 // ---- work decomposition ----------------------------------------------------------------
@@ -245,6 +373,7 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->chunk_spp = (o && o->chunk_spp > 0) ? std::min(o->chunk_spp, samples) : default_chunk_spp(j->n_tiles, samples);
   j->n_chunks = (samples + j->chunk_spp - 1) / j->chunk_spp;
   j->spp = samples;
+  j->s_first = 0;
   return GRT_OK;
 }
 
@@ -256,13 +385,14 @@ GRT_API uint64_t grt_accum_workspace_bytes(const grt_scene* s, const grt_opts* o
   return (uint64_t)j.n_chunks * (uint64_t)j.rows_local * (uint64_t)s->d.width * 3u * sizeof(float);
 }
 
-GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
-                                 float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count,
-                                 void* stream) {
+static int render_dev(grt_scene* s, const grt_opts* o, int shard, int n_shards, int sample_first, int samples, float* d_rgb_sum,
+                      void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
   if (!s || !d_rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_dev: NULL scene or output");
+  if (sample_first < 0) return grt_fail(GRT_EINVAL, "first sample must not be negative (got %d)", sample_first);
   RenderJob j;
   int rc = make_job(s, o, shard, n_shards, samples, &j);
   if (rc) return rc;
+  j.s_first = sample_first;
   if (j.rows_local == 0) return GRT_OK;
   const uint64_t need = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
   if (need > workspace_bytes || (need && !d_workspace))
@@ -278,7 +408,9 @@ GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard,
   // opts->flags bits 0-3: kernel variant for A/B timing (0 = default)
   const int variant = o ? (o->flags & 15) : 0;
   unsigned long long* rcnt = (unsigned long long*)d_ray_count;
-  if (!scene_is_small(s) || variant == 1)
+  if (s->use_bvh)
+    hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  else if (!scene_is_small(s) || variant == 1)
     hipLaunchKernelGGL((k_pathtrace<0, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (variant == 2)  // object reads hoisted out of the wave loop (115 VGPRs, 4 waves/SIMD): slower
     hipLaunchKernelGGL((k_pathtrace<GRT_FAST_PRIMS, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
@@ -294,6 +426,20 @@ GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard,
     GRT_HIP(hipGetLastError());
   }
   return GRT_OK;
+}
+
+GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
+                                 float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count,
+                                 void* stream) {
+  return render_dev(s, o, shard, n_shards, 0, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream);
+}
+
+// Sample-range sharding: the whole frame, samples [sample_first, sample_first + samples) of every
+// pixel.  The RNG is keyed by the absolute sample index, so the ranks' frames add up to the frame
+// a single device renders (up to the order of the FP32 additions across ranks).
+GRT_API int grt_render_accum_samples_dev(grt_scene* s, const grt_opts* o, int32_t sample_first, int32_t samples, float* d_rgb_sum,
+                                         void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
+  return render_dev(s, o, 0, 1, sample_first, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream);
 }
 
 GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows, int32_t samples, uint8_t* d_bgrx,
@@ -479,7 +625,10 @@ GRT_API int grt_trace_samples(grt_scene* s, const grt_opts* o, const int32_t* pi
     TRY(hipMalloc(&d_rgb, n * 3 * sizeof(float)));
     TRY(hipMalloc(&d_nr, n * sizeof(int)));
     TRY(hipMemcpy(d_xy, pixel_xy, (size_t)n_pixels * 2 * sizeof(int), hipMemcpyHostToDevice));
-    if (scene_is_small(s))
+    if (s->use_bvh)
+      hipLaunchKernelGGL(k_trace_samples<-1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, ks, d_xy, n_pixels,
+                         samples, d_rgb, d_nr);
+    else if (scene_is_small(s))
       hipLaunchKernelGGL(k_trace_samples<GRT_FAST_PRIMS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, ks, d_xy,
                          n_pixels, samples, d_rgb, d_nr);
     else
@@ -557,7 +706,10 @@ GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t sampl
   int rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
   if (rc) return rc;
   const int tiles = ((ks.W + 7) / 8) * ((ks.H + 7) / 8);
-  if (scene_is_small(s) && o && (o->flags & 15) == 3)
+  if (s->use_bvh)
+    hipLaunchKernelGGL(k_primary_sweep<-1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
+                       d_checksum);
+  else if (scene_is_small(s) && o && (o->flags & 15) == 3)
     hipLaunchKernelGGL((k_primary_sweep<GRT_FAST_PRIMS, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        ks, samples, d_checksum);
   else if (scene_is_small(s) && !(o && (o->flags & 15) == 1))

@@ -82,6 +82,10 @@ struct KScene {
   const float4* __restrict__ prims;
   const float4* __restrict__ mats;
   const float4* __restrict__ lights;
+  // scenes above GRT_MAX_LINEAR_PRIMS objects (or grt_scene_desc.accel = GRT_ACCEL_BVH): grt_bvh.h
+  const float4* __restrict__ bvh_nodes;
+  const float4* __restrict__ bvh_prims;
+  const int* __restrict__ bvh_ids;
 };
 
 #define GRT_MAT_TRANSPARENT 1
@@ -252,6 +256,8 @@ GRT_DEV bool refract32(f3 v, f3 n, float eta_ratio, float xi, f3& out) {
   out = unit3(fma3(rn, k, r1));
   return true;
 }
+
+#include "grt_bvh.h"
 
 // ---- one camera path as a per-lane state machine ------------------------------------------
 // Scene.trace (scene.go:237-349) is recursive with at most max_depth-1 levels and every level
@@ -427,7 +433,7 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 // sample s_end-1.  n_rays counts intersect() calls (scene.go:242).
 template <int NP, bool RELOAD = false, bool PREFETCH = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
-                          uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays) {
+                          uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
   if (RELOAD) asm volatile("" ::: "memory");
@@ -435,7 +441,10 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   ray_setup_unit(r, L.O, L.D);
   float t;
   int id;
-  if (__builtin_expect(__any(ray_has_zero(r)), 0))
+  if (NP < 0)  // NP < 0: bounding-volume hierarchy (grt_bvh.h), per-lane stack in LDS
+    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack, 256)
+                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack, 256);
+  else if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
   else if (NP > 0)
     id = intersect_lds<NP, PREFETCH>(tp, S.box_mask, r, S.bias, t);

@@ -13,6 +13,7 @@
 // The linear-scan kernels (the reference's own algorithm, scene.go:173) read every object
 // for every ray; beyond this many objects a scene goes through the BVH path instead.
 #define GRT_MAX_LINEAR_PRIMS 4096
+#define GRT_MAX_PRIMS (1 << 26)
 
 int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
@@ -27,6 +28,9 @@ struct DeviceScene {
   float4* mats = nullptr;
   float4* lights = nullptr;
   double* prims64 = nullptr;
+  float4* bvh_nodes = nullptr;  // grt_bvh.h; NULL for linear-scan scenes
+  float4* bvh_prims = nullptr;
+  int* bvh_ids = nullptr;
 };
 
 struct grt_scene {
@@ -36,6 +40,7 @@ struct grt_scene {
   std::vector<int> lights;    // scene.go:42-46
   std::vector<int> tobjects;  // scene.go:48-50
   double light_area = 0.0;
+  bool use_bvh = false;
   std::mutex mu;
   std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
 };

@@ -18,6 +18,7 @@ struct RenderJob {
   int rows_local;       // rows this shard owns (packed, ascending)
   int tiles_x, n_tiles; // 8x8 tiles across, and in total for this shard
   int n_chunks, chunk_spp, spp;
+  int s_first;          // first sample index (sample-range sharding; 0 otherwise)
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -66,6 +67,7 @@ template <int NP, bool RELOAD = false, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
   SceneTables<NP> T;
   load_tables<NP>(S, lds, T);
   const int lane = threadIdx.x & 63;
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
   const int lrow = lband * 8 + (lane >> 3);
   const bool valid = (x < S.W) & (y < S.H);
 
-  const int s0 = chunk * J.chunk_spp;
-  const int s_end = min(s0 + J.chunk_spp, J.spp);
+  const int s0 = J.s_first + chunk * J.chunk_spp;
+  const int s_end = min(s0 + J.chunk_spp, J.s_first + J.spp);
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
   const float fx = (float)x, fy = (float)y;
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
   LaneState L;
   lane_begin(S, fx, fy, pix_key, s0, L);
   while (__any(alive)) {
-    if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays);
+    if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x);
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __re
                                                        int samples, float* __restrict__ rgb,
                                                        int* __restrict__ n_rays_out) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];
   SceneTables<NP> T;
   load_tables<NP>(S, lds, T);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __re
   int n_rays = 0;
   bool alive = valid;
   while (__any(alive)) {
-    if (alive) path_advance<NP>(S, T.tp, T.tm, fx, fy, pix_key, s + 1, L, alive, n_rays);
+    if (alive) path_advance<NP>(S, T.tp, T.tm, fx, fy, pix_key, s + 1, L, alive, n_rays, bvh_stack + threadIdx.x);
   }
   if (valid) {
     rgb[i * 3 + 0] = L.acc.x;
@@ -195,7 +198,15 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   Ray32 r;
   ray_setup(r, O, D);
   float t;
-  int id = intersect32(S, r, t);
+  int id;
+  __shared__ int bvh_stack[GRT_BVH_STACK * 256];
+  if (S.bvh_nodes) {  // large scenes: FP32 through the hierarchy; the FP64 re-test (a linear scan) is not run
+    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256)
+                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256);
+    force_mode = 1;
+  } else {
+    id = intersect32(S, r, t);
+  }
   f3 p, nn = mk3(0.0f, 0.0f, 0.0f);
   if (id >= 0) surface32(S, id, r, t, p, nn);
   else t = 0.0f;
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
 template <int NP, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];
   SceneTables<NP> T;
   load_tables<NP>(S, lds, T);
   const int lane = threadIdx.x & 63;
@@ -249,7 +261,10 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
     ray_setup(r, O, D);
     float t;
     int id;
-    if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
+    if (NP < 0)
+      id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256)
+                                  : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256);
+    else if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
     else if (NP > 0) id = intersect_lds<NP, PREFETCH>(T.tp, S.box_mask, r, S.bias, t);
     else id = intersect32_t<false>(S, r, t);
     sum += (uint32_t)(id + 1);

@@ -297,6 +297,8 @@ static int pick_device(const grt_opts* o, int* dev) {
 GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) {
   if (!s || !out || max_photons <= 0) return grt_fail(GRT_EINVAL, "grt_photon_build: bad argument");
   if (s->lights.empty()) return grt_fail(GRT_EINVAL, "grt_photon_build: the scene has no light (Emittance > 0)");
+  if (s->use_bvh)  // photons are stored on plain-diffuse surfaces only (scene.go:413-422), which a BVH scene cannot hold
+    return grt_fail(GRT_ELIMIT, "grt_photon_build: photon emission runs on linear-scan scenes (<= %d objects)", GRT_MAX_LINEAR_PRIMS);
   int dev;
   int rc = pick_device(o, &dev);
   if (rc) return rc;

@@ -88,3 +88,45 @@ class ShardRenderer:
         stream = torch.cuda.current_stream(frame_sum.device).cuda_stream
         check(self.lib.grt_tonemap_dev(frame_sum.data_ptr(), w, h, self.samples, out.data_ptr(), 4 * w, stream))
         return out
+
+
+def sample_range(samples, rank, world):
+    """Samples [first, first + count) of every pixel rendered by `rank`."""
+    first = samples * rank // world
+    return first, samples * (rank + 1) // world - first
+
+
+class SampleShardRenderer:
+    """Sample-range sharding: every rank renders the whole frame for its share of the sample
+    indices (the scene is replicated: the mode for scenes that stress memory, config C5) and the
+    FP32 sums are added with one RCCL reduce to rank 0."""
+
+    def __init__(self, scene, samples, rank=0, world=1, seed=1, chunk_spp=0, device=None):
+        self.lib = load()
+        self.scene, self.samples, self.rank, self.world = scene, int(samples), rank, world
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.opts = scene.opts(seed=seed, chunk_spp=chunk_spp)
+        self.first, self.count = sample_range(self.samples, rank, world)
+        self.rgb_sum = torch.zeros((scene.H, scene.W, 3), dtype=torch.float32, device=self.device)
+        nbytes = int(self.lib.grt_accum_workspace_bytes(scene.handle, C.byref(self.opts), 0, 1, max(1, self.count)))
+        self.workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        self.workspace_bytes = nbytes
+        self.ray_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.render()  # stages the scene on this device so that later calls never allocate
+        torch.cuda.synchronize(self.device)
+        self.ray_count.zero_()
+
+    def render(self):
+        if self.count == 0:
+            self.rgb_sum.zero_()
+            return
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.grt_render_accum_samples_dev(self.scene.handle, C.byref(self.opts), self.first, self.count,
+                                                    self.rgb_sum.data_ptr(), self.workspace.data_ptr(),
+                                                    self.workspace_bytes, self.ray_count.data_ptr(), stream))
+
+    def reduce(self, dst=0):
+        """Sum of the ranks' frames on rank dst ([H, W, 3] float32), this rank's own buffer elsewhere."""
+        if self.world > 1:
+            dist.reduce(self.rgb_sum, dst=dst, op=dist.ReduceOp.SUM)
+        return self.rgb_sum

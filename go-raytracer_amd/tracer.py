@@ -147,7 +147,7 @@ def NewCamera(eye, lookat, vup, vfov, aspect):
 
 
 # ---- flattening: Scene.Objects []Hitable -> POD arrays ------------------------------
-def flatten(width, height, cam, objects, max_depth=MAX_DEPTH, bias=BIAS):
+def flatten(width, height, cam, objects, max_depth=MAX_DEPTH, bias=BIAS, accel=0):
     """The type switch the cgo shim performs: one grt_prim per object in
     Scene.Objects order (the index is the object id), materials de-duplicated by value."""
     mats, mat_index = [], {}
@@ -179,8 +179,33 @@ def flatten(width, height, cam, objects, max_depth=MAX_DEPTH, bias=BIAS):
         r.transparent, r.lambert, r.normal = int(m.Transparent), int(m.Lambert), int(m.Normal)
     desc = SceneDesc()
     desc.width, desc.height, desc.max_depth, desc.bias = width, height, max_depth, bias
+    desc.accel = accel
     desc.cam = cam
     return desc, prims, len(objects), mrec, len(mats)
+
+
+PRIM_DTYPE = np.dtype([("kind", "<i4"), ("material", "<i4"), ("a", "<f8", 3), ("b", "<f8", 3), ("radius", "<f8")])
+assert PRIM_DTYPE.itemsize == C.sizeof(PrimRec)
+
+
+def flatten_arrays(width, height, cam, prim_array, materials, max_depth=MAX_DEPTH, bias=BIAS, accel=0):
+    """The same POD arrays from a numpy record array (PRIM_DTYPE) and a list of Material: the bulk
+    route for scenes of millions of objects (config C5), where one Python object per sphere is
+    too slow.  prim_array[i] is object i of Scene.Objects."""
+    prim_array = np.ascontiguousarray(prim_array, PRIM_DTYPE)
+    prims = (PrimRec * max(1, prim_array.shape[0])).from_buffer(prim_array) if prim_array.shape[0] else (PrimRec * 1)()
+    mrec = (MaterialRec * max(1, len(materials)))()
+    for i, m in enumerate(materials):
+        r = mrec[i]
+        r.color[:] = m.Color
+        r.refr_index, r.reflectivity, r.roughness = m.RefrIndex, m.Reflectivity, m.Roughness
+        r.emittance = m.Emittance
+        r.transparent, r.lambert, r.normal = int(m.Transparent), int(m.Lambert), int(m.Normal)
+    desc = SceneDesc()
+    desc.width, desc.height, desc.max_depth, desc.bias = width, height, max_depth, bias
+    desc.accel = accel
+    desc.cam = cam
+    return desc, prims, int(prim_array.shape[0]), mrec, len(materials)
 
 
 def _ptr(a):
@@ -191,16 +216,23 @@ class Scene:
     """tracer.Scene (scene.go:17-27) staged on the GPU behind a grt_scene handle."""
 
     def __init__(self, width, height, cam, objects, globalPmap=None, causticPmap=None,
-                 max_depth=MAX_DEPTH, bias=BIAS):
-        self.W, self.H, self.Cam, self.Objects = int(width), int(height), cam, list(objects)
+                 max_depth=MAX_DEPTH, bias=BIAS, accel=0, flat=None):
+        self.W, self.H, self.Cam = int(width), int(height), cam
+        self.Objects = list(objects) if objects is not None else None
         self.globalPmap, self.causticPmap = globalPmap, causticPmap
         self.maxDepth = max_depth
-        self.flat = flatten(self.W, self.H, cam, self.Objects, max_depth, bias)
+        self.flat = flat if flat is not None else flatten(self.W, self.H, cam, self.Objects, max_depth, bias, accel)
         self._lib = load()
         h = C.c_void_p()
         desc, prims, n_prims, mats, n_mats = self.flat
         check(self._lib.grt_scene_create(C.byref(desc), prims, n_prims, mats, n_mats, C.byref(h)))
         self.handle = h
+
+    @classmethod
+    def from_flat(cls, flat):
+        """Scene from the POD arrays of flatten() / flatten_arrays()."""
+        desc = flat[0]
+        return cls(desc.width, desc.height, desc.cam, None, max_depth=desc.max_depth, bias=desc.bias, flat=flat)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -243,13 +275,16 @@ class Scene:
                                           _ptr(rgb), _ptr(nr)))
         return rgb, nr
 
-    def PrimaryHits(self, jitter_mode=_capi.GRT_JITTER_CENTER, seed=1):
+    def PrimaryHits(self, jitter_mode=_capi.GRT_JITTER_CENTER, seed=1, mode=0):
+        """mode: 0 = FP32 with FP64 re-test of ambiguous lanes, 1 = FP32 only, 2 = FP64 only
+        (scenes that use the hierarchy always run FP32 only)."""
         n = self.W * self.H
         ids = np.empty(n, np.int32)
         t = np.empty(n, np.float32)
         nrm = np.empty((n, 3), np.float32)
         fb = C.c_uint64(0)
         o = self.opts(seed)
+        o.flags = (int(mode) & 3) << 8
         check(self._lib.grt_primary_hits(self.handle, C.byref(o), jitter_mode, _ptr(ids), _ptr(t),
                                          _ptr(nrm), C.byref(fb)))
         return ids.reshape(self.H, self.W), t.reshape(self.H, self.W), nrm.reshape(self.H, self.W, 3), fb.value

@@ -82,10 +82,17 @@ typedef struct {
   int32_t width;     /* Scene.W */
   int32_t height;    /* Scene.H */
   int32_t max_depth; /* Scene.maxDepth, 6 in NewScene (scene.go:62) */
-  int32_t _pad;
+  int32_t accel;     /* GRT_ACCEL_*; no counterpart in the reference (it scans linearly, scene.go:173) */
   double bias; /* 0.001 (scene.go:14) */
   grt_camera cam;
 } grt_scene_desc;
+
+/* How Scene.intersect finds the nearest object.  AUTO: the reference's linear scan up to 4096
+ * objects, a bounding-volume hierarchy above (same result, see csrc/grt_bvh.h); BVH forces the
+ * hierarchy (tests).  Scenes that use the hierarchy cannot hold plain DiffuseMaterial objects
+ * (their shadow loop, scene.go:336-344, is order-dependent) and do not emit photons. */
+#define GRT_ACCEL_AUTO 0
+#define GRT_ACCEL_BVH 1
 
 /* Run options.  The reference seeds every worker with time.Now().Unix() (scene.go:114);
  * here the seed is explicit and keys a counter-based RNG (pixel, sample, dimension). */
@@ -136,6 +143,13 @@ int grt_render_accum(grt_scene* scene, const grt_opts* opts, float* rgb_sum, int
 int grt_render_accum_dev(grt_scene* scene, const grt_opts* opts, int32_t shard, int32_t n_shards,
                          int32_t samples, float* d_rgb_sum, void* d_workspace,
                          uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream);
+/* Sample-range sharding: the WHOLE frame, samples
+ * [sample_first, sample_first + samples) of every pixel (the s of scene.go:92), linear RGB
+ * sums to d_rgb_sum (float32 [height*width*3]).  Workspace: grt_accum_workspace_bytes(scene,
+ * opts, 0, 1, samples).  The frames of disjoint ranges add up to the frame of the union. */
+int grt_render_accum_samples_dev(grt_scene* scene, const grt_opts* opts, int32_t sample_first,
+                                 int32_t samples, float* d_rgb_sum, void* d_workspace,
+                                 uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream);
 int32_t grt_shard_rows(int32_t height, int32_t shard, int32_t n_shards);
 uint64_t grt_accum_workspace_bytes(const grt_scene* scene, const grt_opts* opts, int32_t shard,
                                    int32_t n_shards, int32_t samples);

@@ -1,0 +1,98 @@
+"""Scene.intersect through the bounding-volume hierarchy (csrc/grt_bvh.h, config C5) against the
+linear scan the reference performs (scene.go:169-181): same object ids, same images."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def both(pkg, w, h, objs):
+    cam = pkg.scenes.cornell_camera(w / h)
+    lin = pkg.tracer.Scene(w, h, cam, objs)
+    bvh = pkg.tracer.Scene(w, h, cam, objs, accel=pkg._capi.GRT_ACCEL_BVH)
+    return lin, bvh
+
+
+@pytest.mark.parametrize("n_s,n_b,seed", [(0, 0, 1), (30, 30, 2), (300, 0, 3), (0, 300, 4), (600, 600, 5)])
+def test_primary_ids_equal_the_linear_scan(pkg, ob, n_s, n_b, seed):
+    objs = pkg.scenes.random_objects(n_s, n_b, seed, diffuse=False)
+    lin, bvh = both(pkg, 512, 512, objs)
+    for jitter in (0, 1):
+        li, lt, ln, _ = lin.PrimaryHits(jitter, seed, mode=1)      # FP32 only: the arithmetic the hierarchy shares
+        bi, bt, bn, _ = bvh.PrimaryHits(jitter, seed)
+        assert (li == bi).all(), f"{(li != bi).sum()} ids differ from the FP32 linear scan"
+        assert (lt == bt).all() and (ln == bn).all()
+        rid, rt, rn = ob.OracleScene(lin.flat).PrimaryHits(jitter, seed)
+        assert (bi != rid).mean() < 2e-4                            # float64 reference: FP32 silhouette pixels only
+        hit = (rid >= 0) & (bi == rid)
+        assert (np.abs(bt[hit] - rt[hit]) / rt[hit]).max() < 1e-4
+
+
+def test_paths_equal_the_linear_scan(pkg):
+    """Same RNG, same per-object arithmetic, order-free nearest hit: every sample's radiance and
+    path length equal the linear kernel's."""
+    objs = pkg.scenes.random_objects(150, 150, 9, diffuse=False)
+    lin, bvh = both(pkg, 96, 96, objs)
+    xy = np.stack(np.meshgrid(np.arange(0, 96, 3), np.arange(0, 96, 3)), -1).reshape(-1, 2)
+    lr, ln = lin.TraceSamples(xy, 16, seed=4)
+    br, bn = bvh.TraceSamples(xy, 16, seed=4)
+    same = (ln == bn) & (lr == br).all(-1)
+    assert same.mean() > 0.999, same.mean()
+    a = lin.RenderAccum(32, seed=2)
+    b = bvh.RenderAccum(32, seed=2)
+    assert np.abs(a - b).max() <= 1e-3 * a.max() or (a == b).mean() > 0.999
+
+
+def test_tiny_and_degenerate_scenes(pkg, ob):
+    m = pkg.tracer.LambertMaterial((0.5, 0.5, 0.5))
+    for objs in ([pkg.tracer.NewSphere((278, 278, 300), 100, m)],
+                 [pkg.tracer.NewAABB((100, 100, 100), (400, 400, 400), m)],
+                 pkg.scenes.cornell_objects()[:3],
+                 [pkg.tracer.NewSphere((278, 278, 300), 100, m)] * 9):      # coincident objects: lowest index wins
+        lin, bvh = both(pkg, 64, 64, objs)
+        li, lt, ln, _ = lin.PrimaryHits(0, 1, mode=1)
+        bi, bt, bn, _ = bvh.PrimaryHits(0, 1)
+        assert (li == bi).all() and (lt == bt).all()
+        assert bi.max() <= 0 or len(objs) != 9                               # nine copies: id 0 everywhere
+
+
+def test_origin_inside_and_entry_within_bias(pkg, ob):
+    """aabb.go:44 returns the entry distance: a box the ray starts inside is no hit, a box
+    entered within the bias wins over everything behind it.  Camera inside / just in front of boxes."""
+    T = pkg.tracer
+    m = T.LambertMaterial((0.5, 0.5, 0.5))
+    eye = (278.0, 273.0, -800.0)
+    objs = [T.NewAABB((0, 0, 100), (555, 555, 200), m),
+            T.NewAABB((200, 200, -900), (350, 350, -700), m),                # contains the eye
+            T.NewAABB((0, 0, -799.9995), (555, 555, -700), m),               # entered at t ~ 0.0005 < bias
+            T.NewSphere((278, 278, 400), 150, m)] + pkg.scenes.random_objects(40, 40, 3, diffuse=False)[6:]
+    lin, bvh = both(pkg, 128, 128, objs)
+    li, lt, _, _ = lin.PrimaryHits(1, 2, mode=1)
+    bi, bt, _, _ = bvh.PrimaryHits(1, 2)
+    rid, _, _ = ob.OracleScene(lin.flat).PrimaryHits(1, 2)
+    assert (li == bi).all() and (lt == bt).all()
+    assert (bi == rid).mean() > 0.999
+    assert (bi == 2).mean() > 0.5                                             # the quirk box wins where it is entered
+
+
+def test_c5_spheres_scene_at_test_size(pkg, ob):
+    """C5 generator at 6000 spheres (above the linear-scan limit, so AUTO picks the hierarchy):
+    ids against the float64 oracle's linear scan, image mean against the oracle's."""
+    scene = pkg.scenes.spheres(6000, 160, 90)
+    ref = ob.OracleScene(scene.flat)
+    ids, t, nrm, _ = scene.PrimaryHits(0, 1)
+    rid, rt, rn = ref.PrimaryHits(0, 1)
+    assert (ids != rid).mean() < 5e-4
+    hit = (rid >= 0) & (ids == rid)
+    assert (np.abs(t[hit] - rt[hit]) / rt[hit]).max() < 1e-4
+    assert np.abs(nrm[hit] - rn[hit]).max() < 2e-3                           # radius ~1 at distance ~1000: FP32 normal error
+    a = scene.RenderAccum(16, seed=1).astype(np.float64) / 16
+    b = ref.RenderAccum(16, seed=1) / 16
+    rel = np.abs(a.mean((0, 1)) - b.mean((0, 1))) / b.mean((0, 1))
+    assert (rel < 0.03).all(), rel
+
+
+def test_diffuse_material_is_refused_with_the_hierarchy(pkg):
+    objs = pkg.scenes.random_objects(5, 5, 1, diffuse=True)
+    with pytest.raises(pkg._capi.GrtError, match="DiffuseMaterial"):
+        pkg.tracer.Scene(32, 32, pkg.scenes.cornell_camera(1.0), objs, accel=pkg._capi.GRT_ACCEL_BVH)

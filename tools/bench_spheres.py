@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Config C5: synthetic N-sphere scene (SURVEY.md §8d `spheres1M`) at 1920x1080, 256 spp, through
+the bounding-volume hierarchy.  Single GPU here; `--gpus N` under torch.distributed.run shards the
+SAMPLE range over the ranks and sums the FP32 frames with one RCCL reduce.
+    python tools/bench_spheres.py [--spheres 1000000] [--spp 256] [--steps 3]
+Prints one JSON line (rank 0)."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("go-raytracer_amd")
+shard = importlib.import_module("go-raytracer_amd.shard")
+ap = argparse.ArgumentParser()
+ap.add_argument("--spheres", type=int, default=1000000)
+ap.add_argument("--spp", type=int, default=256)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--cpu-spheres", type=int, default=10000)
+a = ap.parse_args()
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+dev = torch.device("cuda", torch.cuda.current_device())
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+W, H = a.width, a.height
+t0 = time.perf_counter()
+scene = pkg.scenes.spheres(a.spheres, W, H)
+t_create = time.perf_counter() - t0
+t0 = time.perf_counter()
+ren = shard.SampleShardRenderer(scene, a.spp, rank, world, seed=1, device=dev)   # stages the scene: BVH build + upload
+t_stage = time.perf_counter() - t0
+torch.cuda.synchronize()
+times = []
+for k in range(a.steps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    w0 = time.perf_counter()
+    e0.record()
+    ren.render()
+    e1.record()
+    frame = ren.reduce(0)
+    torch.cuda.synchronize()
+    times.append((time.perf_counter() - w0, e0.elapsed_time(e1)))
+wall = sorted(t[0] for t in times)[len(times) // 2]
+kms = sorted(t[1] for t in times)[len(times) // 2]
+rays = float(ren.ray_count.item()) / a.steps
+if world > 1:
+    st = torch.tensor([wall, rays], dtype=torch.float64, device=dev)
+    mx = st.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = st.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    wall, rays = mx[0].item(), sm[1].item()
+if rank == 0:
+    out = {"workload": f"C5: {a.spheres} spheres + light box + floor, {W}x{H}, {a.spp} spp, depth cap 6, seed 1, BVH",
+           "n_gpus": world, "sharding": "sample range per rank, RCCL reduce(sum) of the FP32 frame" if world > 1 else "none",
+           "scene_create_s": t_create, "stage_s_incl_bvh_build_and_first_frame": t_stage,
+           "frame_s": wall, "kernel_ms_rank0": kms, "Msamples_per_s": W * H * a.spp / wall / 1e6,
+           "rays_per_s": rays / wall, "rays_per_sample": rays / (W * H * a.spp),
+           "mean_radiance": frame.mean((0, 1)).div(a.spp).tolist()}
+    if a.cpu_spheres > 0 and world == 1:
+        from oracle import binding as ob
+        cw, ch, cspp = 160, 90, 2
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+        o = ob.OracleScene(pkg.scenes.spheres_flat(a.cpu_spheres, cw, ch))
+        t0 = time.perf_counter()
+        o.RenderAccum(cspp, seed=1, nthreads=threads)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"Msamples_per_s": cw * ch * cspp / dt / 1e6, "cores": threads, "kind": "port",
+                               "sample": f"{a.cpu_spheres} spheres (linear scan as scene.go:173), {cw}x{ch}, {cspp} spp, {dt:.1f} s",
+                               "extrapolated_to_scene_Msamples_per_s": cw * ch * cspp / dt / 1e6 * a.cpu_spheres / a.spheres,
+                               "note": "the reference's cost is linear in the object count; extrapolation is x N_cpu/N"}
+    print(json.dumps(out))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
