@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of one profile set from gpurun_out/<tag>/ into profiles/ (tracked):
+    python profiles/collect.py r01b r01
+kernel_stats (first rows), the bench JSON line of each traced run, the PMC summaries of this
+repo's kernels, and profiles/traffic.json (HBM bytes per k_pathtrace launch, read by bench.py)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+for cfg in ("c2", "c3", "c4", "c5"):
+    ks = glob.glob(os.path.join(src, f"trace_{cfg}", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        lines = open(ks[0]).read().splitlines()[:9]
+        open(os.path.join(dst, f"{name}_{cfg}_kernel_stats.csv"), "w").write("\n".join(lines) + "\n")
+    log = os.path.join(src, f"trace_{cfg}.log")
+    if os.path.exists(log):
+        js = [l for l in open(log, errors="replace") if l.startswith("{")]
+        if js:
+            open(os.path.join(dst, f"{name}_{cfg}_bench_under_trace.json"), "w").write(js[-1])
+    pm = os.path.join(src, f"pmc_{cfg}")
+    if os.path.isdir(pm):
+        out = subprocess.run([sys.executable, os.path.join(dst, "summarize_pmc.py"), pm], capture_output=True, text=True, check=True).stdout
+        open(os.path.join(dst, f"{name}_{cfg}_pmc.json"), "w").write(out)
+        if cfg == "c3":
+            d = json.loads(out).get("k_pathtrace<8, true, false>", {})
+            if "hbm_write_bytes" in d:
+                # k_pathtrace stores 12 B per pixel per chunk with dword stores (WRITE_SIZE is exact for those)
+                # and reads only the 0.5 KB scene: FETCH_SIZE raw (no wide coalesced reads to correct for)
+                json.dump({"k_pathtrace_hbm_bytes_per_launch": d["hbm_write_bytes"] + d.get("hbm_read_bytes_raw", 0.0),
+                           "read_bytes": d.get("hbm_read_bytes_raw"), "write_bytes": d["hbm_write_bytes"],
+                           "source": f"profiles/{name}_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB units)",
+                           "config": "1920x1080, 1000 spp, 1 GPU"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print("collected", sorted(os.listdir(dst)))

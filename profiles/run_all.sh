@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profile set (run on the GPU box from the repo root):  bash profiles/run_all.sh <tag>
+# Kernel-trace summaries for the four measured configs, then PMC passes for C3 and C4.
+# Results under gpurun_out/<tag>/; profiles/collect.py copies the summaries into profiles/.
+set -u
+TAG=${1:-r01b}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+trace() { # name script args...
+  local name=$1; shift
+  timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$name" -- python3 "$@" > "$OUT/trace_$name.log" 2>&1
+  local rc=$?
+  echo "trace $name rc=$rc"
+  return $rc
+}
+trace c3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline || exit 1
+trace c2 "$ROOT/tools/bench_primary.py" --rounds 5 || exit 1
+trace c4 "$ROOT/tools/bench_photon.py" --cpu-queries 0 --rounds 5 || exit 1
+trace c5 "$ROOT/tools/bench_spheres.py" --steps 2 --cpu-spheres 0 || exit 1
+cd "$ROOT"
+bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > "$OUT/pmc_c3.log" 2>&1 || exit 1
+bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c4 tools/bench_photon.py --cpu-queries 0 --rounds 2 > "$OUT/pmc_c4.log" 2>&1 || exit 1
+bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c2 tools/bench_primary.py --rounds 2 > "$OUT/pmc_c2.log" 2>&1 || exit 1
+echo done

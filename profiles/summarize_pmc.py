@@ -18,10 +18,10 @@ for f in glob.glob(f"{out}/*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        m = re.search(r"\bk_[a-z_0-9]+", name)
+        m = re.match(r"(?:void )?(k_[a-z_0-9]+(?:<[^>]*>)?)\(", name)
         if not m:
             continue
-        short = m.group(0) + ("<" + name.split("<", 1)[1].split(">")[0] + ">" if "<" in name else "")
+        short = m.group(1)
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
         key = (f, row["Dispatch_Id"])
         if key not in seen:

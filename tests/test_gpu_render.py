@@ -112,3 +112,28 @@ def test_errors_are_reported(pkg):
     xy = np.array([[40, 0]], np.int32)
     with pytest.raises(pkg._capi.GrtError):
         scene.TraceSamples(xy, 1)
+
+
+def test_sample_range_frames_add_up(pkg):
+    """grt_render_accum_samples_dev (sample-range sharding): the frames of the
+    ranges [0,5), [5,12), [12,16) sum to the 16-spp frame; each sample is keyed by its absolute index."""
+    import importlib
+
+    import torch
+
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    W, H, S = 96, 64, 16
+    scene = pkg.scenes.cornell(W, H)
+    full = torch.from_numpy(scene.RenderAccum(S, seed=3)).cuda()
+    total = torch.zeros_like(full)
+    rays = 0
+    for first, count in ((0, 5), (5, 7), (12, 4)):
+        ren = shard.SampleShardRenderer(scene, S, 0, 1, seed=3)
+        ren.first, ren.count = first, count
+        ren.ray_count.zero_()
+        ren.render()
+        torch.cuda.synchronize()
+        total += ren.rgb_sum
+        rays += int(ren.ray_count.item())
+    assert torch.allclose(total, full, rtol=1e-5, atol=1e-6)
+    assert rays == scene.last_ray_count()

@@ -66,3 +66,49 @@ def test_band_rows_match_library(pkg):
                 assert len(owned[r]) == lib.grt_shard_rows(h, r, g)
             assert shard.max_shard_rows(h, g) == max(len(o) for o in owned)
     assert shard.band_rows(52, 1, 2)[:9] == [8, 9, 10, 11, 12, 13, 14, 15, 24]
+
+
+def _sample_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("go-raytracer_amd")
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    from oracle import binding as ob
+
+    w, h, spp = 12, 10, 7
+    s = ob.OracleScene(pkg.scenes.cornell_flat(w, h))
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2)
+    rgb, _ = s.TraceSamples(xy, spp, seed=5)               # [pixel, sample, 3]: sample s is keyed by its absolute index
+    first, count = shard.sample_range(spp, rank, world)
+    ren = object.__new__(shard.SampleShardRenderer)        # the reduce step only (render() needs a GPU)
+    ren.world = world
+    ren.rgb_sum = torch.from_numpy(rgb[:, first:first + count].sum(1).reshape(h, w, 3).astype(np.float32))
+    frame = ren.reduce(0)
+    if rank == 0:
+        q.put((frame.numpy(), rgb.sum(1).reshape(h, w, 3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sample_range_reduce_equals_single_process(world):
+    """Sample-range sharding (config C5): the ranks' partial frames add up to the whole frame."""
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    for spp in (1, 7, 256):
+        for g in (1, 2, 3, 8):
+            parts = [shard.sample_range(spp, r, g) for r in range(g)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(g - 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_sample_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame, full = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(frame, full, rtol=1e-6, atol=1e-7)

@@ -72,7 +72,7 @@ if rank == 0:
            "mean_radiance": frame.mean((0, 1)).div(a.spp).tolist()}
     if a.cpu_spheres > 0 and world == 1:
         from oracle import binding as ob
-        cw, ch, cspp = 160, 90, 2
+        cw, ch, cspp = 640, 360, 8
         threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
         o = ob.OracleScene(pkg.scenes.spheres_flat(a.cpu_spheres, cw, ch))
         t0 = time.perf_counter()
