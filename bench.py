@@ -36,7 +36,7 @@ def cpu_baseline(pkg, width, height):
     from oracle import binding as ob
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    spp = 8
+    spp = 32
     s = ob.OracleScene(pkg.scenes.cornell_flat(width, height))
     s.RenderAccum(1, seed=1, row_begin=0, row_end=min(64, height), nthreads=threads)  # warm up threads / caches
     t0 = time.perf_counter()

@@ -274,6 +274,23 @@ struct LaneState {
   uint32_t pkey; // RNG key of the current path
   int depth;     // scene.go:237 `depth` of the ray in flight (1 = primary)
   int s;         // sample index of the current path
+  int pix;       // wave-queue mode: which of the tile's 64 pixels the current path belongs to
+};
+
+// Wave-queue mode (k_pathtrace): the (pixel, sample) pairs of a wave's tile x chunk form one
+// queue; a lane whose path ends takes the NEXT pair of the queue instead of the next sample of
+// "its" pixel, so all lanes run out of work within one path length of each other (per-pixel
+// sample loops drain at the pace of the slowest pixel).  MEASURED SLOWER than the per-pixel loops
+// at C3 (45.9 ms vs 44.1 ms: 92 VGPRs instead of 76, and the drain it removes is small next to the
+// divergence inside a level), so it is an A/B variant (opts.flags & 15 == 4), not the default.  A path's
+// radiance is added to its pixel's sum in LDS when it ends.  Element q of the queue is sample
+// s0 + q / 64 of pixel q % 64; the assignment depends only on the wave's own paths, so a frame
+// is reproducible and independent of how it is sharded.
+struct WaveQueue {
+  int next, qend;          // same value in every live lane
+  int s0, x0, y0;          // first sample of the chunk, tile origin
+  float* acc;              // LDS: 64 x RGB sums of this wave's tile
+  const uint32_t* pixkey;  // LDS: RNG pixel keys of the tile's 64 pixels
 };
 
 // Ray with |D| = 1: a = inva = 1 fold away inside sphere_hit32.
@@ -431,9 +448,10 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
 // arrays of S and the loop runs over S.n_prims.  `alive` turns false when the lane has finished
 // sample s_end-1.  n_rays counts intersect() calls (scene.go:242).
-template <int NP, bool RELOAD = false, bool PREFETCH = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
-                          uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr) {
+                          uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr,
+                          WaveQueue* Q = nullptr) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
   if (RELOAD) asm volatile("" ::: "memory");
@@ -485,13 +503,36 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
       else dir = unit3(dir);                        // keep |D| = 1 (direction unchanged)
     }
   }
-  L.acc = mk3(fmaf(L.thr.x, rad.x, L.acc.x), fmaf(L.thr.y, rad.y, L.acc.y), fmaf(L.thr.z, rad.z, L.acc.z));
-  if (term) {                                       // next sample of this pixel (scene.go:92)
-    L.s++;
-    alive = L.s < s_end;
-    L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
-    L.depth = 0;
-    L.thr = mk3(1.0f, 1.0f, 1.0f);
+  if (QUEUE) {
+    // only a terminating level carries radiance (emission, NormalMaterial, direct light)
+    const f3 c = L.thr * rad;
+    if (term & ((c.x != 0.0f) | (c.y != 0.0f) | (c.z != 0.0f))) {
+      atomicAdd(Q->acc + 3 * L.pix, c.x);
+      atomicAdd(Q->acc + 3 * L.pix + 1, c.y);
+      atomicAdd(Q->acc + 3 * L.pix + 2, c.z);
+    }
+    const unsigned long long ended = __ballot(term);  // every live lane sees the same mask
+    const int q = Q->next + __builtin_amdgcn_mbcnt_hi((uint32_t)(ended >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ended, 0));
+    Q->next += __builtin_popcountll(ended);
+    if (term) {                                     // next (pixel, sample) of the wave's queue
+      alive = q < Q->qend;
+      L.pix = q & 63;
+      L.s = Q->s0 + (q >> 6);
+      pix_key = Q->pixkey[L.pix];
+      fx = (float)(Q->x0 + (L.pix & 7)), fy = (float)(Q->y0 + (L.pix >> 3));
+      L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
+      L.depth = 0;
+      L.thr = mk3(1.0f, 1.0f, 1.0f);
+    }
+  } else {
+    L.acc = mk3(fmaf(L.thr.x, rad.x, L.acc.x), fmaf(L.thr.y, rad.y, L.acc.y), fmaf(L.thr.z, rad.z, L.acc.z));
+    if (term) {                                     // next sample of this pixel (scene.go:92)
+      L.s++;
+      alive = L.s < s_end;
+      L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
+      L.depth = 0;
+      L.thr = mk3(1.0f, 1.0f, 1.0f);
+    }
   }
   const uint32_t base = term ? GRT_DIM_JITTER_U : GRT_DIM_HIT(L.depth, 0);
   const float u1 = grt_rng_draw(L.pkey, base), u2 = grt_rng_draw(L.pkey, base + 1u);

@@ -63,11 +63,13 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
 // in the same loop iteration, so every iteration of the wave-wide loop does one intersect()
 // for every lane that still has samples left — terminated paths never leave idle lanes
 // behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
-template <int NP, bool RELOAD = false, bool PREFETCH = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
+  __shared__ float qacc[QUEUE ? 4 * 192 : 1];                  // wave-queue mode: [wave][pixel][rgb]
+  __shared__ uint32_t qkey[QUEUE ? 4 * 64 : 1];
   SceneTables<NP> T;
   load_tables<NP>(S, lds, T);
   const int lane = threadIdx.x & 63;
@@ -82,21 +84,44 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
 
   const int s0 = J.s_first + chunk * J.chunk_spp;
   const int s_end = min(s0 + J.chunk_spp, J.s_first + J.spp);
-  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
-  const float fx = (float)x, fy = (float)y;
+  uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  float fx = (float)x, fy = (float)y;
 
   int n_rays = 0;
   bool alive = valid & (s0 < s_end);
   LaneState L;
   lane_begin(S, fx, fy, pix_key, s0, L);
-  while (__any(alive)) {
-    if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x);
+  f3 result;
+  if (QUEUE) {
+    // The wave's (pixel, sample) pairs are one queue (see WaveQueue).  Lanes of pixels outside
+    // the frame (edge tiles) take part: their paths are traced and dropped.
+    const int w = threadIdx.x >> 6;
+    WaveQueue Q;
+    Q.acc = qacc + 192 * w, Q.pixkey = qkey + 64 * w;
+    Q.acc[3 * lane] = 0.0f, Q.acc[3 * lane + 1] = 0.0f, Q.acc[3 * lane + 2] = 0.0f;
+    qkey[64 * w + lane] = pix_key;
+    Q.s0 = s0, Q.x0 = tx * 8, Q.y0 = (J.shard + lband * J.n_shards) * 8;
+    Q.next = 64, Q.qend = 64 * (s_end - s0);
+    L.pix = lane;
+    alive = s0 < s_end;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (__any(alive)) {
+      if (alive)
+        path_advance<NP, RELOAD, PREFETCH, true>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x, &Q);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    result = mk3(Q.acc[3 * lane], Q.acc[3 * lane + 1], Q.acc[3 * lane + 2]);
+  } else {
+    while (__any(alive)) {
+      if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x);
+    }
+    result = L.acc;
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
-    o[0] = L.acc.x;
-    o[1] = L.acc.y;
-    o[2] = L.acc.z;
+    o[0] = result.x;
+    o[1] = result.y;
+    o[2] = result.z;
   }
   if (ray_count) {
     unsigned long long tot = wave_sum_u32((unsigned)n_rays);
