@@ -4,8 +4,8 @@
 //                    + Store's direction quantisation                photon_mapping.go:165-193
 //   k_photon_scatter ordered compaction of the stored photons + ScalePhotonPower's scale
 //                    (photon_mapping.go:197-206)
-//   upload_tree()    kdtree.New(list, true) (photon_mapping.go:207): balanced median splits into
-//                    leaf buckets, collapsed to a 64-ary tree of bounding boxes
+//   build_tree_device  kdtree.New(list, true) (photon_mapping.go:207): balanced median splits into
+//                    leaf buckets (one radix sort per level), collapsed to a 64-ary tree of boxes
 //   k_gather_knn     NearestSet + NKeeper(k) (photon_mapping.go:131-133) and the loop of
 //                    IrradianceEst (photon_mapping.go:138-161), one wave per query
 //
@@ -38,7 +38,7 @@
 //   pos3[3i] = x, y, z           what the search reads: a leaf bucket is 64 x 12 B, contiguous
 //   pwb[i]   = (r, g, b, bits)   what an accepted photon adds: power (already scaled by
 //                                1000/max) and direction bytes, bits = theta << 8 | phi << 16
-//   boxes[i], boxes[n_boxes+i]  min / max corners of the 64-ary tree's node boxes (see upload_tree)
+//   boxes[i], boxes[n_boxes+i]  min / max corners of the 64-ary tree's node boxes (see build_tree_device)
 #define KD_LEAF 64
 #define KD_FAN_BITS 6
 struct grt_pmap {
@@ -48,7 +48,7 @@ struct grt_pmap {
   float4* d_pwb = nullptr;   // [n+1]
   float4* d_boxes = nullptr; // [2 * n_boxes]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
-  std::vector<int> order;    // slot -> storage (emission) index, for grt_photon_read
+  int* d_order = nullptr;    // [n+1] slot -> storage (emission) index (grt_photon_read)
 };
 
 // ---- emission ---------------------------------------------------------------------------------
@@ -173,7 +173,15 @@ __global__ __launch_bounds__(256) void k_photon_scatter(const int* __restrict__ 
   if (slot == max - 1) *last_emit = i;
 }
 
-// ---- bucket kd-tree (host build) ------------------------------------------------------------
+#define PTRY(x)                                                                     \
+  {                                                                                 \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      rc = grt_fail(GRT_EHIP, "%s: %s", #x, hipGetErrorString(e_));                 \
+      break;                                                                        \
+    }                                                                               \
+  }
+// ---- bucket kd-tree (device build) ----------------------------------------------------------
 // kdtree.New(list, true) (photon_mapping.go:207) builds a balanced tree; here the balanced
 // tree is `depth` levels of median splits (axis of largest extent) that sort the photons into
 // 2^depth leaf buckets of 33..64 photons.  Leaf j owns the contiguous slots
@@ -184,105 +192,193 @@ __global__ __launch_bounds__(256) void k_photon_scatter(const int* __restrict__ 
 // stream).  Level l holds 2^(b0 + 6 l) boxes, b0 = depth - 6 (levels - 1); the last level's
 // boxes are the leaves'.  boxes[i] = (min.xyz, 0), boxes[n_boxes + i] = (max.xyz, 0), levels
 // concatenated, so the first GATHER_LDS_BOXES records (the top levels) are one LDS copy.
-struct HostPhoton {
-  float p[3];
-  float pw[3];
-  int bits, src;
-};
+//
+// The photons never leave the device.  Level l of the build: (1) bounding box of each of the
+// 2^l segments (wave reduction + one atomic min/max per wave and axis, on order-preserving
+// integer images of the floats), (2) split axis per segment, (3) one radix sort of all photons
+// by (segment, coordinate on the segment's axis): segments are contiguous and a segment's two
+// halves are the next level's segments, so after `depth` sorts every bucket holds its photons.
+// n = 10^7: 18 sorts of 64-bit keys with 4-byte values (hipCUB), tens of milliseconds.
+GRT_DEV uint32_t ordered_bits(float f) {  // a < b  <=>  ordered_bits(a) < ordered_bits(b)
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+GRT_DEV float ordered_float(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
+// bucket that owns slot p: the largest j with (j*n >> depth) <= p
+GRT_DEV int kd_leaf_of(int p, int n, int depth) { return (int)(((((long long)p + 1) << depth) - 1) / (long long)n); }
 static inline int leaf_start(long long j, int n, int depth) { return (int)((j * (long long)n) >> depth); }
 
-static void kd_split(const std::vector<HostPhoton>& ph, std::vector<int>& idx, int leaf_lo, int leaf_hi, int n, int depth,
-                     int par_depth) {
-  if (leaf_hi - leaf_lo <= 1) return;
-  const int lo = leaf_start(leaf_lo, n, depth), hi = leaf_start(leaf_hi, n, depth);
-  const int leaf_mid = (leaf_lo + leaf_hi) >> 1, mid = leaf_start(leaf_mid, n, depth);
-  float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
-  for (int i = lo; i < hi; ++i)
-    for (int k = 0; k < 3; ++k) {
-      float v = ph[idx[i]].p[k];
-      mn[k] = std::min(mn[k], v), mx[k] = std::max(mx[k], v);
+__global__ __launch_bounds__(256) void k_kd_iota(int* __restrict__ perm, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) perm[p] = p;
+}
+
+// segbox[3 seg + c] = min, segbox[3 S + 3 seg + c] = max of coordinate c (ordered images).
+__global__ __launch_bounds__(256) void k_kd_bbox(const float4* __restrict__ pos, const int* __restrict__ perm, int n, int depth,
+                                                 int level, int n_seg, uint32_t* __restrict__ segbox) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = p < n;
+  const int seg = kd_leaf_of(valid ? p : n - 1, n, depth) >> (depth - level);
+  uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+  if (valid) {
+    const float4 q = pos[perm[p]];
+    lo[0] = hi[0] = ordered_bits(q.x), lo[1] = hi[1] = ordered_bits(q.y), lo[2] = hi[2] = ordered_bits(q.z);
+  }
+  const int seg0 = __builtin_amdgcn_readfirstlane(seg);
+  if (__all(seg == seg0)) {  // the usual case: the wave lies inside one segment
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[c] = min(lo[c], (uint32_t)__shfl_xor((int)lo[c], off, 64));
+        hi[c] = max(hi[c], (uint32_t)__shfl_xor((int)hi[c], off, 64));
+      }
     }
-  int ax = 0;  // split axis: largest extent of the segment
-  if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
-  if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
-  auto cmp = [&](int a, int b) {
-    float x = ph[a].p[ax], y = ph[b].p[ax];
-    return x < y || (x == y && a < b);
-  };
-  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, cmp);
-  if (par_depth > 0 && hi - lo > 8192) {
-    auto fut = std::async(std::launch::async,
-                          [&, leaf_lo, leaf_mid, par_depth] { kd_split(ph, idx, leaf_lo, leaf_mid, n, depth, par_depth - 1); });
-    kd_split(ph, idx, leaf_mid, leaf_hi, n, depth, par_depth - 1);
-    fut.get();
-  } else {
-    kd_split(ph, idx, leaf_lo, leaf_mid, n, depth, 0);
-    kd_split(ph, idx, leaf_mid, leaf_hi, n, depth, 0);
+    if ((threadIdx.x & 63) == 0)
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(segbox + 3 * seg0 + c, lo[c]);
+        atomicMax(segbox + 3 * n_seg + 3 * seg0 + c, hi[c]);
+      }
+  } else if (valid) {
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(segbox + 3 * seg + c, lo[c]);
+      atomicMax(segbox + 3 * n_seg + 3 * seg + c, hi[c]);
+    }
   }
 }
 
-static int upload_tree(std::vector<HostPhoton>& ph, grt_pmap* pm) {
-  const int n = (int)ph.size();
+__global__ __launch_bounds__(256) void k_kd_keys(const float4* __restrict__ pos, const int* __restrict__ perm, int n, int depth,
+                                                 int level, int n_seg, const uint32_t* __restrict__ segbox,
+                                                 unsigned long long* __restrict__ keys) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int seg = kd_leaf_of(p, n, depth) >> (depth - level);
+  float ext[3];
+  for (int c = 0; c < 3; ++c) ext[c] = ordered_float(segbox[3 * n_seg + 3 * seg + c]) - ordered_float(segbox[3 * seg + c]);
+  int ax = 0;  // split axis: largest extent of the segment
+  if (ext[1] > ext[ax]) ax = 1;
+  if (ext[2] > ext[ax]) ax = 2;
+  const float4 q = pos[perm[p]];
+  const float v = ax == 0 ? q.x : (ax == 1 ? q.y : q.z);
+  keys[p] = ((unsigned long long)(uint32_t)seg << 32) | (unsigned long long)ordered_bits(v);
+}
+
+// Photon records in bucket order + the leaf boxes: one wave per bucket.
+__global__ __launch_bounds__(256) void k_kd_finalize(const float4* __restrict__ pos, const float4* __restrict__ pow,
+                                                     const int* __restrict__ perm, int n, int depth, float* __restrict__ pos3,
+                                                     float4* __restrict__ pwb, float4* __restrict__ box_lo,
+                                                     float4* __restrict__ box_hi) {
+  const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (leaf >= (1 << depth)) return;
+  const int a = (int)(((long long)leaf * n) >> depth), b = (int)(((long long)(leaf + 1) * n) >> depth);
+  const int p = a + lane;
+  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};  // an empty bucket is never within any bound
+  if (p < b) {
+    const int src = perm[p];
+    const float4 q = pos[src], w = pow[src];
+    pos3[3 * (size_t)p] = q.x, pos3[3 * (size_t)p + 1] = q.y, pos3[3 * (size_t)p + 2] = q.z;
+    pwb[p] = make_float4(w.x, w.y, w.z, q.w);
+    lo[0] = hi[0] = q.x, lo[1] = hi[1] = q.y, lo[2] = hi[2] = q.z;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64));
+      hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64));
+    }
+  }
+  if (lane == 0) {
+    box_lo[leaf] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    box_hi[leaf] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  }
+}
+
+// Box i of a level = union of its 64 children on the level below: one wave per box.
+__global__ __launch_bounds__(256) void k_kd_upbox(const float4* __restrict__ child_lo, const float4* __restrict__ child_hi,
+                                                  int n_parent, float4* __restrict__ par_lo, float4* __restrict__ par_hi) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_parent) return;
+  const float4 a = child_lo[((size_t)i << KD_FAN_BITS) + lane], b = child_hi[((size_t)i << KD_FAN_BITS) + lane];
+  float lo[3] = {a.x, a.y, a.z}, hi[3] = {b.x, b.y, b.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64));
+      hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64));
+    }
+  }
+  if (lane == 0) {
+    par_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    par_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  }
+}
+
+// d_pos[i] = (x, y, z, bits), d_pow[i] = (r, g, b, -) for the n photons in storage order (device).
+static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, grt_pmap* pm) {
   int depth = 0;
   while (((long long)KD_LEAF << depth) < n) depth++;
   const int levels = std::max(1, (depth + KD_FAN_BITS - 1) / KD_FAN_BITS);
   const int b0 = depth - KD_FAN_BITS * (levels - 1);
-  std::vector<int> idx(n);
-  for (int i = 0; i < n; ++i) idx[i] = i;
-  if (n > 0) kd_split(ph, idx, 0, 1 << depth, n, depth, 4);
-  std::vector<float> pos3(3 * ((size_t)n + 1), 0.0f);
-  std::vector<float4> pwb((size_t)n + 1);
-  pm->order.assign((size_t)n, -1);
-  for (int i = 0; i < n; ++i) {
-    const HostPhoton& h = ph[idx[i]];
-    pos3[3 * (size_t)i] = h.p[0], pos3[3 * (size_t)i + 1] = h.p[1], pos3[3 * (size_t)i + 2] = h.p[2];
-    pwb[i] = make_float4(h.pw[0], h.pw[1], h.pw[2], __builtin_bit_cast(float, h.bits));
-    pm->order[i] = h.src;
-  }
-  pwb[n] = make_float4(0, 0, 0, 0);
-  // boxes, bottom level first (leaves), then unions of 64 children going up
   std::vector<size_t> off(levels);
   size_t total = 0;
   for (int l = 0; l < levels; ++l) off[l] = total, total += (size_t)1 << (b0 + KD_FAN_BITS * l);
-  std::vector<float4> boxes(2 * total);
-  for (long long j = 0; j < (1ll << depth); ++j) {
-    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};  // an empty leaf is never within any bound
-    for (int i = leaf_start(j, n, depth); i < leaf_start(j + 1, n, depth); ++i) {
-      for (int c = 0; c < 3; ++c) mn[c] = std::min(mn[c], pos3[3 * (size_t)i + c]), mx[c] = std::max(mx[c], pos3[3 * (size_t)i + c]);
-    }
-    boxes[off[levels - 1] + j] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-    boxes[total + off[levels - 1] + j] = make_float4(mx[0], mx[1], mx[2], 0.0f);
-  }
-  for (int l = levels - 2; l >= 0; --l)
-    for (size_t i = 0; i < ((size_t)1 << (b0 + KD_FAN_BITS * l)); ++i) {
-      float4 mn = make_float4(3e38f, 3e38f, 3e38f, 0.0f), mx = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);
-      for (size_t c = i << KD_FAN_BITS; c < ((i + 1) << KD_FAN_BITS); ++c) {
-        const float4 a = boxes[off[l + 1] + c], b = boxes[total + off[l + 1] + c];
-        mn.x = std::min(mn.x, a.x), mn.y = std::min(mn.y, a.y), mn.z = std::min(mn.z, a.z);
-        mx.x = std::max(mx.x, b.x), mx.y = std::max(mx.y, b.y), mx.z = std::max(mx.z, b.z);
-      }
-      boxes[off[l] + i] = mn, boxes[total + off[l] + i] = mx;
-    }
+  pm->n = n, pm->depth = depth, pm->levels = levels, pm->b0 = b0, pm->n_boxes = (int)total;
   std::vector<float> lut(4 * 256);
   for (int i = 0; i < 256; ++i) {  // photon_mapping.go:105-111
     double angle = (double)i * (1.0 / 256.0) * M_PI;
     lut[i] = (float)cos(angle), lut[256 + i] = (float)sin(angle);
     lut[512 + i] = (float)cos(2.0 * angle), lut[768 + i] = (float)sin(2.0 * angle);
   }
-  pm->n = n;
-  pm->depth = depth;
-  pm->levels = levels;
-  pm->b0 = b0;
-  pm->n_boxes = (int)total;
-  GRT_HIP(hipMalloc(&pm->d_pos3, pos3.size() * sizeof(float)));
-  GRT_HIP(hipMalloc(&pm->d_pwb, pwb.size() * sizeof(float4)));
+  GRT_HIP(hipMalloc(&pm->d_pos3, 3 * ((size_t)n + 1) * sizeof(float)));
+  GRT_HIP(hipMalloc(&pm->d_pwb, ((size_t)n + 1) * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_lut, lut.size() * sizeof(float)));
-  GRT_HIP(hipMalloc(&pm->d_boxes, boxes.size() * sizeof(float4)));
-  GRT_HIP(hipMemcpy(pm->d_pos3, pos3.data(), pos3.size() * sizeof(float), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(pm->d_pwb, pwb.data(), pwb.size() * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMalloc(&pm->d_boxes, 2 * total * sizeof(float4)));
+  GRT_HIP(hipMalloc(&pm->d_order, ((size_t)n + 1) * sizeof(int)));
   GRT_HIP(hipMemcpy(pm->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(pm->d_boxes, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice));
-  return GRT_OK;
+  GRT_HIP(hipMemset(pm->d_boxes, 0, 2 * total * sizeof(float4)));
+  if (n == 0) return GRT_OK;
+  unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
+  int* d_p1 = nullptr;
+  uint32_t* d_segbox = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = GRT_OK;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  do {
+    PTRY(hipMalloc(&d_k0, (size_t)n * sizeof(unsigned long long)));
+    PTRY(hipMalloc(&d_k1, (size_t)n * sizeof(unsigned long long)));
+    PTRY(hipMalloc(&d_p1, (size_t)n * sizeof(int)));
+    PTRY(hipMalloc(&d_segbox, 6 * ((size_t)1 << std::max(0, depth - 1)) * sizeof(uint32_t)));
+    int* perm_in = pm->d_order;
+    int* perm_out = d_p1;
+    PTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, perm_in, perm_out, n, 0, 64));
+    PTRY(hipMalloc(&d_tmp, tmp_bytes));
+    hipLaunchKernelGGL(k_kd_iota, dim3(grid), dim3(256), 0, nullptr, perm_in, n);
+    for (int level = 0; level < depth; ++level) {
+      const int n_seg = 1 << level;
+      PTRY(hipMemsetAsync(d_segbox, 0xff, 3 * (size_t)n_seg * sizeof(uint32_t), nullptr));
+      PTRY(hipMemsetAsync(d_segbox + 3 * (size_t)n_seg, 0, 3 * (size_t)n_seg * sizeof(uint32_t), nullptr));
+      hipLaunchKernelGGL(k_kd_bbox, dim3(grid), dim3(256), 0, nullptr, d_pos, perm_in, n, depth, level, n_seg, d_segbox);
+      hipLaunchKernelGGL(k_kd_keys, dim3(grid), dim3(256), 0, nullptr, d_pos, perm_in, n, depth, level, n_seg, d_segbox, d_k0);
+      PTRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, perm_in, perm_out, n, 0, 32 + level));
+      std::swap(perm_in, perm_out);
+    }
+    if (rc) break;
+    if (perm_in != pm->d_order) PTRY(hipMemcpyAsync(pm->d_order, perm_in, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, nullptr));
+    hipLaunchKernelGGL(k_kd_finalize, dim3((unsigned)(((1 << depth) + 3) / 4)), dim3(256), 0, nullptr, d_pos, d_pow, pm->d_order, n,
+                       depth, pm->d_pos3, pm->d_pwb, pm->d_boxes + off[levels - 1], pm->d_boxes + total + off[levels - 1]);
+    for (int l = levels - 2; l >= 0; --l) {
+      const int n_parent = 1 << (b0 + KD_FAN_BITS * l);
+      hipLaunchKernelGGL(k_kd_upbox, dim3((unsigned)((n_parent + 3) / 4)), dim3(256), 0, nullptr, pm->d_boxes + off[l + 1],
+                         pm->d_boxes + total + off[l + 1], n_parent, pm->d_boxes + off[l], pm->d_boxes + total + off[l]);
+    }
+    PTRY(hipGetLastError());
+    PTRY(hipDeviceSynchronize());
+  } while (0);
+  (void)hipFree(d_k0), (void)hipFree(d_k1), (void)hipFree(d_p1), (void)hipFree(d_segbox), (void)hipFree(d_tmp);
+  return rc;
 }
 
 static int pick_device(const grt_opts* o, int* dev) {
@@ -310,19 +406,10 @@ GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photon
   float4 *d_rpos = nullptr, *d_rpow = nullptr, *d_opos = nullptr, *d_opow = nullptr;
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
-  std::vector<HostPhoton> ph;
   grt_pmap* pm = new grt_pmap;
   pm->max = max_photons;
   pm->device = dev;
   rc = GRT_OK;
-#define PTRY(x)                                                                     \
-  {                                                                                 \
-    hipError_t e_ = (x);                                                            \
-    if (e_ != hipSuccess) {                                                         \
-      rc = grt_fail(GRT_EHIP, "%s: %s", #x, hipGetErrorString(e_));                 \
-      break;                                                                        \
-    }                                                                               \
-  }
   do {
     PTRY(hipMalloc(&d_flag, BATCH_MAX * sizeof(int)));
     PTRY(hipMalloc(&d_scan, BATCH_MAX * sizeof(int)));
@@ -392,17 +479,7 @@ GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photon
       break;
     }
     pm->emitted = emitted;
-    std::vector<float4> hp(stored), hw(stored);
-    PTRY(hipMemcpy(hp.data(), d_opos, (size_t)stored * sizeof(float4), hipMemcpyDeviceToHost));
-    PTRY(hipMemcpy(hw.data(), d_opow, (size_t)stored * sizeof(float4), hipMemcpyDeviceToHost));
-    ph.resize(stored);
-    for (int i = 0; i < stored; ++i) {
-      ph[i].p[0] = hp[i].x, ph[i].p[1] = hp[i].y, ph[i].p[2] = hp[i].z;
-      memcpy(&ph[i].bits, &hp[i].w, 4);
-      ph[i].pw[0] = hw[i].x, ph[i].pw[1] = hw[i].y, ph[i].pw[2] = hw[i].z;
-      ph[i].src = i;
-    }
-    rc = upload_tree(ph, pm);
+    rc = build_tree_device(d_opos, d_opow, stored, pm);
   } while (0);
   (void)hipFree(d_flag), (void)hipFree(d_scan), (void)hipFree(d_last), (void)hipFree(d_rpos), (void)hipFree(d_rpow);
   (void)hipFree(d_opos), (void)hipFree(d_opow), (void)hipFree(d_tmp);
@@ -420,16 +497,25 @@ GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* po
   int dev;
   int rc = pick_device(o, &dev);
   if (rc) return rc;
-  std::vector<HostPhoton> ph(n);
+  std::vector<float4> hp(std::max(n, 1)), hw(std::max(n, 1));
   for (int i = 0; i < n; ++i) {
-    for (int k = 0; k < 3; ++k) ph[i].p[k] = pos[3 * (size_t)i + k], ph[i].pw[k] = power[3 * (size_t)i + k];
-    ph[i].bits = ((int)theta_phi[2 * (size_t)i] << 8) | ((int)theta_phi[2 * (size_t)i + 1] << 16);
-    ph[i].src = i;
+    const int bits = ((int)theta_phi[2 * (size_t)i] << 8) | ((int)theta_phi[2 * (size_t)i + 1] << 16);
+    hp[i] = make_float4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], __builtin_bit_cast(float, bits));
+    hw[i] = make_float4(power[3 * (size_t)i], power[3 * (size_t)i + 1], power[3 * (size_t)i + 2], 0.0f);
   }
   grt_pmap* pm = new grt_pmap;
   pm->max = n;
   pm->device = dev;
-  rc = upload_tree(ph, pm);
+  float4 *d_p = nullptr, *d_w = nullptr;
+  rc = GRT_OK;
+  do {
+    PTRY(hipMalloc(&d_p, hp.size() * sizeof(float4)));
+    PTRY(hipMalloc(&d_w, hw.size() * sizeof(float4)));
+    PTRY(hipMemcpy(d_p, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PTRY(hipMemcpy(d_w, hw.data(), hw.size() * sizeof(float4), hipMemcpyHostToDevice));
+    rc = build_tree_device(d_p, d_w, n, pm);
+  } while (0);
+  (void)hipFree(d_p), (void)hipFree(d_w);
   if (rc) {
     grt_photon_free(pm);
     return rc;
@@ -449,8 +535,10 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
   std::vector<float4> w4(n + 1);
   GRT_HIP(hipMemcpy(p3.data(), pm->d_pos3, p3.size() * sizeof(float), hipMemcpyDeviceToHost));
   GRT_HIP(hipMemcpy(w4.data(), pm->d_pwb, w4.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  std::vector<int> order(n + 1);
+  GRT_HIP(hipMemcpy(order.data(), pm->d_order, order.size() * sizeof(int), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) {  // back to storage (emission) order
-    const size_t d = (size_t)pm->order[i];
+    const size_t d = (size_t)order[i];
     int bits;
     memcpy(&bits, &w4[i].w, 4);
     if (pos) pos[3 * d] = p3[3 * i], pos[3 * d + 1] = p3[3 * i + 1], pos[3 * d + 2] = p3[3 * i + 2];
@@ -467,6 +555,7 @@ GRT_API void grt_photon_free(grt_pmap* pm) {
     (void)hipFree(pm->d_pwb);
     (void)hipFree(pm->d_lut);
     (void)hipFree(pm->d_boxes);
+    (void)hipFree(pm->d_order);
   }
   delete pm;
 }
