@@ -76,6 +76,11 @@ PROTOTYPES = {
     "grt_photon_count": (C.c_int32, [_vp]),
     "grt_photon_read": (C.c_int, [_vp, _vp, _vp, _vp]),
     "grt_photon_load": (C.c_int, [P(Opts), _vp, _vp, _vp, C.c_int32, P(_vp)]),
+    "grt_photon_emit_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "grt_photon_emit_workspace_bytes": (C.c_uint64, [C.c_int32]),
+    "grt_photon_load_dev": (C.c_int, [P(Opts), _vp, _vp, C.c_int32, C.c_float, C.c_uint64, P(_vp)]),
+    "grt_scene_light_count": (C.c_int32, [_vp]),
+    "grt_scene_light_share": (C.c_int32, [_vp, C.c_int32]),
     "grt_photon_gather": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp]),
     "grt_photon_gather_dev": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp, _vp]),
     "grt_photon_gather_workspace_bytes": (C.c_uint64, [C.c_int32]),
@@ -107,6 +112,15 @@ def load():
     """Load libgrt_hip.so (built by __graft_entry__.build()).  No fallback."""
     global _lib
     if _lib is None:
+        # A process must hold ONE HIP runtime.  torch bundles its own libamdhip64 / libhsa-runtime64;
+        # if /opt/rocm's copy is loaded first (through libgrt_hip.so) and torch's afterwards, the second
+        # HSA runtime finds no GPU ("No HIP GPUs are available").  Loaded after torch, libgrt_hip.so
+        # binds to the runtime already in the process (same SONAME).  shard.py and bench.py use torch
+        # for device memory and process groups, so it goes first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

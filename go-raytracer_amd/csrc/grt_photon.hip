@@ -524,6 +524,109 @@ GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* po
   return GRT_OK;
 }
 
+// ---- emission slices + build from device arrays (photon-build sharding) -------
+// A rank traces the emission indices [first, first + count) of one light and gets its stored
+// photons, compacted in emission order; the ranks' slices are concatenated in rank order (an
+// all-gather, shard.py) and every rank builds the identical tree with grt_photon_load_dev.
+__global__ __launch_bounds__(256) void k_photon_compact(const int* __restrict__ flag, const int* __restrict__ scan, int n_emit,
+                                                        const float4* __restrict__ rec_pos, const float4* __restrict__ rec_pow,
+                                                        float4* __restrict__ out_pos, float4* __restrict__ out_pow,
+                                                        int* __restrict__ n_stored) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_emit) return;
+  if (flag[i]) {
+    const float4 pw = rec_pow[i];
+    out_pos[scan[i]] = rec_pos[i];
+    out_pow[scan[i]] = make_float4(pw.x, pw.y, pw.z, __int_as_float(i));  // .w: offset of its emission inside the slice
+  }
+  if (i == n_emit - 1) *n_stored = scan[i] + flag[i];
+}
+__global__ __launch_bounds__(256) void k_photon_scale(const float4* __restrict__ in, float scale, int n, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float4(in[i].x * scale, in[i].y * scale, in[i].z * scale, 0.0f);
+}
+
+static size_t emit_scan_bytes(int count) {
+  size_t b = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (int*)nullptr, (int*)nullptr, count);
+  return (b + 255) & ~(size_t)255;
+}
+GRT_API uint64_t grt_photon_emit_workspace_bytes(int32_t count) {
+  if (count <= 0) return 0;
+  const size_t c = ((size_t)count + 63) & ~(size_t)63;
+  return 2 * c * sizeof(int) + 2 * c * sizeof(float4) + emit_scan_bytes(count);
+}
+GRT_API int32_t grt_scene_light_count(const grt_scene* s) { return s ? (int32_t)s->lights.size() : 0; }
+// int(lightArea / area) of light k: how many times `max` photons that light's loop aims for (scene.go:152,157).
+GRT_API int32_t grt_scene_light_share(const grt_scene* s, int32_t k) {
+  if (!s || k < 0 || k >= (int)s->lights.size()) return 0;
+  const grt_material& m = s->mats[s->prims[s->lights[k]].material];
+  return (int32_t)(s->light_area / (m.color[0] + m.color[1] + m.color[2]));
+}
+
+GRT_API int grt_photon_emit_dev(grt_scene* s, const grt_opts* o, int32_t caustics, int32_t light, uint64_t first, int32_t count,
+                                float* d_pos4, float* d_pow4, int32_t* d_stored, void* d_workspace, uint64_t workspace_bytes,
+                                void* stream) {
+  if (!s || !d_pos4 || !d_pow4 || !d_stored || count <= 0) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: bad argument");
+  if (light < 0 || light >= (int)s->lights.size()) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: light %d of %zu", light, s->lights.size());
+  if (s->use_bvh) return grt_fail(GRT_ELIMIT, "grt_photon_emit_dev: photon emission runs on linear-scan scenes");
+  if (!d_workspace || workspace_bytes < grt_photon_emit_workspace_bytes(count))
+    return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: workspace %llu bytes, need %llu", (unsigned long long)workspace_bytes,
+                    (unsigned long long)grt_photon_emit_workspace_bytes(count));
+  KScene ks;
+  int rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
+  if (rc) return rc;
+  const size_t c = ((size_t)count + 63) & ~(size_t)63;
+  int* d_flag = (int*)d_workspace;
+  int* d_scan = d_flag + c;
+  float4* d_rpos = (float4*)(d_scan + c);
+  float4* d_rpow = d_rpos + c;
+  void* d_tmp = (void*)(d_rpow + c);
+  size_t tmp_bytes = emit_scan_bytes(count);
+  const grt_prim& lp = s->prims[s->lights[light]];
+  double pos[3];
+  for (int k = 0; k < 3; ++k) pos[k] = lp.kind == GRT_KIND_AABB ? (lp.b[k] + lp.a[k]) * 0.5 : lp.a[k];
+  const float4 lpos = make_float4((float)pos[0], (float)pos[1], (float)pos[2], 0.0f);
+  const float3 power0 = caustics ? make_float3(1.0f, 1.0f, 1.0f) : make_float3(15.0f, 15.0f, 15.0f);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((count + 255) / 256);
+  hipLaunchKernelGGL(k_photon_trace, dim3(grid), dim3(256), 0, st, ks, lpos, power0, caustics, (unsigned long long)first, count, d_flag,
+                     d_rpos, d_rpow);
+  GRT_HIP(hipGetLastError());
+  GRT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, count, st));
+  hipLaunchKernelGGL(k_photon_compact, dim3(grid), dim3(256), 0, st, d_flag, d_scan, count, d_rpos, d_rpow, (float4*)d_pos4,
+                     (float4*)d_pow4, d_stored);
+  GRT_HIP(hipGetLastError());
+  return GRT_OK;
+}
+
+GRT_API int grt_photon_load_dev(const grt_opts* o, const float* d_pos4, const float* d_pow4, int32_t n, float power_scale,
+                                uint64_t emitted, grt_pmap** out) {
+  if (n < 0 || !out || (n > 0 && (!d_pos4 || !d_pow4))) return grt_fail(GRT_EINVAL, "grt_photon_load_dev: bad argument");
+  int dev;
+  int rc = pick_device(o, &dev);
+  if (rc) return rc;
+  grt_pmap* pm = new grt_pmap;
+  pm->max = n;
+  pm->device = dev;
+  pm->emitted = emitted;
+  float4* d_w = nullptr;
+  rc = GRT_OK;
+  do {
+    PTRY(hipMalloc(&d_w, (size_t)std::max(n, 1) * sizeof(float4)));
+    if (n > 0) hipLaunchKernelGGL(k_photon_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const float4*)d_pow4, power_scale, n, d_w);
+    PTRY(hipGetLastError());
+    rc = build_tree_device((const float4*)d_pos4, d_w, n, pm);
+  } while (0);
+  (void)hipFree(d_w);
+  if (rc) {
+    grt_photon_free(pm);
+    return rc;
+  }
+  *out = pm;
+  return GRT_OK;
+}
+
 GRT_API int32_t grt_photon_count(const grt_pmap* pm) { return pm ? pm->n : 0; }
 GRT_API uint64_t grt_photon_emitted(const grt_pmap* pm) { return pm ? pm->emitted : 0; }
 

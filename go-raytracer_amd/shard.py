@@ -130,3 +130,83 @@ class SampleShardRenderer:
         if self.world > 1:
             dist.reduce(self.rgb_sum, dst=dst, op=dist.ReduceOp.SUM)
         return self.rgb_sum
+
+
+# ---- photon-build sharding: emission index ranges per rank, all-gather ------------
+def gather_slices(pos4, pow4, count, rank, world, group=None):
+    """pos4, pow4: [slice, 4] float32 tensors whose first `count` rows are this rank's stored photons
+    (emission order).  Returns (pos, pow, global_offset) of ALL ranks' photons concatenated in rank
+    order = emission order; global_offset[i] = offset of photon i's emission inside the batch
+    (rank * slice + the offset grt_photon_emit_dev left in pow4[:, 3])."""
+    n_slice = pos4.shape[0]
+    cnt = torch.tensor([int(count)], dtype=torch.int64, device=pos4.device)
+    if world > 1:
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt, group=group)
+        poss = [torch.empty_like(pos4) for _ in range(world)]
+        pows = [torch.empty_like(pow4) for _ in range(world)]
+        dist.all_gather(poss, pos4, group=group)
+        dist.all_gather(pows, pow4, group=group)
+    else:
+        cnts, poss, pows = [cnt], [pos4], [pow4]
+    out_pos, out_pow, out_off = [], [], []
+    for r in range(world):
+        c = int(cnts[r].item())
+        out_pos.append(poss[r][:c])
+        out_pow.append(pows[r][:c])
+        out_off.append(pows[r][:c, 3].contiguous().view(torch.int32).to(torch.int64) + r * n_slice)
+    return torch.cat(out_pos), torch.cat(out_pow), torch.cat(out_off)
+
+
+def build_photon_map_sharded(scene, max_photons, caustics=False, rank=0, world=1, seed=1, device=None,
+                             batch_max=1 << 22, gather=gather_slices):
+    """mapPhotons for one map (scene.go:140-165) with the emission loop's iterations dealt to the
+    ranks: every batch of emission indices is cut into `world` consecutive slices, rank g traces
+    slice g (grt_photon_emit_dev), the stored photons are all-gathered in rank order (= emission
+    order), and every rank keeps the first `max` stores and builds the identical map
+    (grt_photon_load_dev).  The result equals grt_photon_build's on one GPU."""
+    from .tracer import PhotonMap
+
+    lib = load()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    opts = scene.opts(seed=seed)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    slice_max = max(256, batch_max // world)
+    ws = torch.empty(int(lib.grt_photon_emit_workspace_bytes(slice_max)), dtype=torch.uint8, device=device)
+    pos4 = torch.zeros((slice_max, 4), dtype=torch.float32, device=device)
+    pow4 = torch.zeros((slice_max, 4), dtype=torch.float32, device=device)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=device)
+    kept_pos, kept_pow = [], []
+    stored, emitted = 0, 0
+    for light in range(int(lib.grt_scene_light_count(scene.handle))):
+        target = min(max_photons, max_photons * int(lib.grt_scene_light_share(scene.handle, light)))
+        yield_, empty = 0.0, 0
+        while stored < target:
+            remaining = target - stored
+            want = int(remaining / yield_ * 1.05 + 4096) if yield_ > 0 else max(65536, 2 * remaining)
+            n_slice = min(slice_max, max(256, -(-want // world)))
+            check(lib.grt_photon_emit_dev(scene.handle, C.byref(opts), int(caustics), light, emitted + rank * n_slice, n_slice,
+                                          pos4.data_ptr(), pow4.data_ptr(), d_cnt.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+            p, w, off = gather(pos4[:n_slice], pow4[:n_slice], int(d_cnt.item()), rank, world)
+            got = p.shape[0]
+            if stored + got >= target:                       # Store's cap (photon_mapping.go:166): the first `target` stores
+                keep = target - stored
+                p, w = p[:keep], w[:keep]
+                emitted += int(off[keep - 1].item()) + 1     # the loop ends with the store that fills the map
+                stored = target
+            else:
+                emitted += n_slice * world
+                stored += got
+            kept_pos.append(p.clone())
+            kept_pow.append(w.clone())
+            yield_ = max(1e-6, got / (n_slice * world))
+            empty = 0 if got else empty + 1
+            if empty >= 64:
+                raise RuntimeError(f"no photon stored in {emitted} emissions (no DiffuseMaterial surface reachable?)")
+    all_pos = torch.cat(kept_pos).contiguous() if kept_pos else pos4[:0]
+    all_pow = torch.cat(kept_pow).contiguous() if kept_pow else pow4[:0]
+    h = C.c_void_p()
+    torch.cuda.synchronize(device)
+    check(lib.grt_photon_load_dev(C.byref(opts), all_pos.data_ptr(), all_pow.data_ptr(), stored, 1000.0 / max_photons, emitted,
+                                  C.byref(h)))
+    return PhotonMap(max_photons, h)

@@ -205,6 +205,24 @@ int grt_photon_read(const grt_pmap* pmap, float* pos, float* power, uint8_t* the
 /* Builds a map from caller-supplied photons instead of emitting (for gather parity). */
 int grt_photon_load(const grt_opts* opts, const float* pos, const float* power,
                     const uint8_t* theta_phi, int32_t n, grt_pmap** out);
+/* Photon-build sharding: a rank traces the emission indices
+ * [first, first + count) of light `light` (the loop body of scene.go:152-160 for those
+ * iterations) and receives its stored photons compacted in emission order: d_pos4[i] =
+ * (x, y, z, direction bytes), d_pow4[i] = (r, g, b unscaled, offset of the emission inside the
+ * slice as int bits), *d_stored = how many.  Outputs hold `count` float4 each.  The slices of
+ * all ranks concatenated in rank order are the reference's store sequence; grt_photon_load_dev
+ * builds the map (power * power_scale = ScalePhotonPower, photon_mapping.go:197-209) from
+ * device arrays.  Device pointers; emit enqueues on `stream` and allocates nothing. */
+int grt_photon_emit_dev(grt_scene* scene, const grt_opts* opts, int32_t caustics, int32_t light,
+                        uint64_t first, int32_t count, float* d_pos4, float* d_pow4,
+                        int32_t* d_stored, void* d_workspace, uint64_t workspace_bytes, void* stream);
+uint64_t grt_photon_emit_workspace_bytes(int32_t count);
+int grt_photon_load_dev(const grt_opts* opts, const float* d_pos4, const float* d_pow4, int32_t n,
+                        float power_scale, uint64_t emitted, grt_pmap** out);
+/* Lights as NewScene derives them (scene.go:42-46): how many, and int(lightArea / area) of
+ * light k, the multiple of `max` its emission loop aims for (scene.go:152,157). */
+int32_t grt_scene_light_count(const grt_scene* scene);
+int32_t grt_scene_light_share(const grt_scene* scene, int32_t k);
 /* IrradianceEst batch (photon_mapping.go:125-162): for each of n queries, the k nearest
  * photons (all photons tied at the k-th distance are kept); radius==0 => use all of them,
  * else those with d^2 < radius^2; sums power of photons with dir.normal < 0, divides by

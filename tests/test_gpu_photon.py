@@ -117,3 +117,55 @@ def test_c4_radiance_gather_on_primary_hits(pkg, ob):
     assert close.mean() > 0.99
     assert np.allclose(a.mean(0), b.mean(0), rtol=1e-3)
     assert (a.sum(1) > 0).mean() > 0.95                          # the walls are lit
+
+
+@pytest.mark.parametrize("caustics,n", [(False, 30000), (True, 2000)])
+def test_sharded_build_equals_single_gpu_build(pkg, caustics, n):
+    """Photon-build sharding: emission index ranges per rank + all-gather.  One GPU
+    here: world = 1 through the sharded code path, and world = 3 with the three ranks' slices traced
+    one after the other by a stand-in for the all-gather.  Both equal grt_photon_build bit for bit."""
+    import importlib
+
+    import torch
+
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    scene = pkg.scenes.cornell(64, 64, "cornell8d")
+    ref = pkg.tracer.PhotonMap(n).build(scene, caustics=caustics, seed=3)
+    rp, rw, rt = ref.read()
+    one = shard.build_photon_map_sharded(scene, n, caustics, 0, 1, seed=3, batch_max=1 << 16)
+    for m in (one,):
+        p, w, t = m.read()
+        assert m.count() == n and m.emitted() == ref.emitted()
+        assert (p == rp).all() and (w == rw).all() and (t == rt).all()
+
+    # three ranks in one process: the gather stand-in traces the other ranks' slices itself
+    lib = pkg._capi.load()
+    import ctypes as C
+
+    def fake_gather(pos4, pow4, count, rank, world):
+        n_slice = pos4.shape[0]
+        # recover `first` of this batch from the call that just ran: rank 0's slice starts at state["emitted"]
+        parts = []
+        for r in range(world):
+            if r == rank:
+                parts.append((pos4.clone(), pow4.clone(), count))
+                continue
+            ws = torch.empty(int(lib.grt_photon_emit_workspace_bytes(n_slice)), dtype=torch.uint8, device=pos4.device)
+            a, b = torch.zeros_like(pos4), torch.zeros_like(pow4)
+            c = torch.zeros(1, dtype=torch.int32, device=pos4.device)
+            o = scene.opts(seed=3)
+            pkg._capi.check(lib.grt_photon_emit_dev(scene.handle, C.byref(o), int(caustics), 0, state["emitted"] + r * n_slice, n_slice,
+                                                    a.data_ptr(), b.data_ptr(), c.data_ptr(), ws.data_ptr(), ws.numel(), None))
+            torch.cuda.synchronize()
+            parts.append((a, b, int(c.item())))
+        pos = torch.cat([x[0][: x[2]] for x in parts])
+        pw = torch.cat([x[1][: x[2]] for x in parts])
+        off = torch.cat([x[1][: x[2], 3].contiguous().view(torch.int32).to(torch.int64) + r * n_slice for r, x in enumerate(parts)])
+        state["emitted"] += n_slice * world
+        return pos, pw, off
+
+    state = {"emitted": 0}
+    three = shard.build_photon_map_sharded(scene, n, caustics, 1, 3, seed=3, batch_max=3 << 14, gather=fake_gather)
+    p, w, t = three.read()
+    assert three.count() == n and three.emitted() == ref.emitted()
+    assert (p == rp).all() and (w == rw).all() and (t == rt).all()
