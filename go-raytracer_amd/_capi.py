@@ -86,6 +86,10 @@ PROTOTYPES = {
     "grt_photon_gather_workspace_bytes": (C.c_uint64, [C.c_int32]),
     "grt_photon_emitted": (C.c_uint64, [_vp]),
     "grt_photon_free": (None, [_vp]),
+    "grt_render_pm": (C.c_int, [_vp, P(Opts), _vp, _vp, _vp, C.c_int32, C.c_int32]),
+    "grt_render_accum_pm": (C.c_int, [_vp, P(Opts), _vp, _vp, _vp, C.c_int32]),
+    "grt_render_accum_pm_dev": (C.c_int, [_vp, P(Opts), _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "grt_render_pm_workspace_bytes": (C.c_uint64, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32]),
     "grt_rng_u01": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grt_last_ray_count": (C.c_uint64, []),
     "grt_last_kernel_ms": (C.c_double, []),

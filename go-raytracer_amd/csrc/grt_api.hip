@@ -374,6 +374,8 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->n_chunks = (samples + j->chunk_spp - 1) / j->chunk_spp;
   j->spp = samples;
   j->s_first = 0;
+  j->pm.pos = j->pm.nrm = j->pm.w = nullptr;
+  j->pm_batch = 0;
   return GRT_OK;
 }
 
@@ -385,14 +387,18 @@ GRT_API uint64_t grt_accum_workspace_bytes(const grt_scene* s, const grt_opts* o
   return (uint64_t)j.n_chunks * (uint64_t)j.rows_local * (uint64_t)s->d.width * 3u * sizeof(float);
 }
 
-static int render_dev(grt_scene* s, const grt_opts* o, int shard, int n_shards, int sample_first, int samples, float* d_rgb_sum,
-                      void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
+int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_shards, int sample_first, int samples,
+                            float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream,
+                            float* pm_pos, float* pm_nrm, float* pm_w, int pm_batch) {
   if (!s || !d_rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_dev: NULL scene or output");
   if (sample_first < 0) return grt_fail(GRT_EINVAL, "first sample must not be negative (got %d)", sample_first);
   RenderJob j;
   int rc = make_job(s, o, shard, n_shards, samples, &j);
   if (rc) return rc;
   j.s_first = sample_first;
+  j.pm.pos = pm_pos, j.pm.nrm = pm_nrm, j.pm.w = pm_w, j.pm_batch = pm_batch;
+  if (pm_pos && (s->use_bvh || pm_batch < samples))
+    return grt_fail(GRT_EINVAL, "photon-mapped render: batch %d < samples %d, or a hierarchy scene", pm_batch, samples);
   if (j.rows_local == 0) return GRT_OK;
   const uint64_t need = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
   if (need > workspace_bytes || (need && !d_workspace))
@@ -433,7 +439,8 @@ static int render_dev(grt_scene* s, const grt_opts* o, int shard, int n_shards, 
 GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
                                  float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count,
                                  void* stream) {
-  return render_dev(s, o, shard, n_shards, 0, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream);
+  return grt_render_dev_internal(s, o, shard, n_shards, 0, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream,
+                                 nullptr, nullptr, nullptr, 0);
 }
 
 // Sample-range sharding: the whole frame, samples [sample_first, sample_first + samples) of every
@@ -441,7 +448,17 @@ GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard,
 // a single device renders (up to the order of the FP32 additions across ranks).
 GRT_API int grt_render_accum_samples_dev(grt_scene* s, const grt_opts* o, int32_t sample_first, int32_t samples, float* d_rgb_sum,
                                          void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
-  return render_dev(s, o, 0, 1, sample_first, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream);
+  return grt_render_dev_internal(s, o, 0, 1, sample_first, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream,
+                                 nullptr, nullptr, nullptr, 0);
+}
+
+// total (+)= frame + photon term of one batch (k_pm_accumulate); used by grt_photon.hip
+int grt_pm_accumulate_internal(const float* frame, const float* qpos, const float* qw, const float* irr_g, const float* irr_c,
+                               int batch, size_t n_pixels, float* total, int first_batch, void* stream) {
+  hipLaunchKernelGGL(k_pm_accumulate, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frame, qpos, qw,
+                     irr_g, irr_c, batch, n_pixels, total, first_batch);
+  GRT_HIP(hipGetLastError());
+  return GRT_OK;
 }
 
 GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows, int32_t samples, uint8_t* d_bgrx,

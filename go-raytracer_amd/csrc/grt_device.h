@@ -286,6 +286,16 @@ struct LaneState {
 // radiance is added to its pixel's sum in LDS when it ends.  Element q of the queue is sample
 // s0 + q / 64 of pixel q % 64; the assignment depends only on the wave's own paths, so a frame
 // is reproducible and independent of how it is sharded.
+// Photon-mapped trace() (scene.go:308-320): a path that ends on a plain diffuse surface leaves one
+// gather request in slot (pixel, sample) of these arrays — position, normal and the weight
+// throughput * m.Color / pi the two irradiance estimates are multiplied by.  A path has at most one
+// such hit (the diffuse branch does not recurse), so the slot is its own and no queue is needed.
+struct PmOut {
+  float* pos;  // [slots * 3], pre-filled with NaN = no request
+  float* nrm;  // [slots * 3]
+  float* w;    // [slots * 3]
+};
+
 struct WaveQueue {
   int next, qend;          // same value in every live lane
   int s0, x0, y0;          // first sample of the chunk, tile origin
@@ -451,7 +461,7 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                           uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr,
-                          WaveQueue* Q = nullptr) {
+                          WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
   if (RELOAD) asm volatile("" ::: "memory");
@@ -489,7 +499,16 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   if (is_emit) rad = color * m1.z;                                                              // scene.go:279
   if (is_normal) rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);      // scene.go:275
   if (__builtin_expect(__any(is_diff), 0)) {
-    if (is_diff) rad = direct_light32(S, p, n, color);                                           // scene.go:322-346
+    if (is_diff) {
+      rad = direct_light32(S, p, n, color);                                                      // scene.go:322-346
+      if (pm && pm->pos) {                                                                       // scene.go:308-320
+        const size_t slot = 3 * (size_t)(pm_base + L.s);
+        const f3 w = (L.thr * color) * 0.318309886183790672f;  // BRDF = 1/pi (:309), Times(m.Color) (:319)
+        pm->pos[slot] = p.x, pm->pos[slot + 1] = p.y, pm->pos[slot + 2] = p.z;
+        pm->nrm[slot] = n.x, pm->nrm[slot + 1] = n.y, pm->nrm[slot + 2] = n.z;
+        pm->w[slot] = w.x, pm->w[slot + 1] = w.y, pm->w[slot + 2] = w.z;
+      }
+    }
   }
   // a scattering material at the last level: the recursive call returns black (scene.go:238)
   bool term = !hit | is_normal | is_emit | is_diff | (L.depth + 1 >= S.max_depth);

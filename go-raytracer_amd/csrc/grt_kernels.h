@@ -19,6 +19,8 @@ struct RenderJob {
   int tiles_x, n_tiles; // 8x8 tiles across, and in total for this shard
   int n_chunks, chunk_spp, spp;
   int s_first;          // first sample index (sample-range sharding; 0 otherwise)
+  PmOut pm;             // photon-mapped trace(): gather requests of this launch (pos == NULL: off)
+  int pm_batch;         // samples per pixel the request arrays hold
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -112,8 +114,11 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     result = mk3(Q.acc[3 * lane], Q.acc[3 * lane + 1], Q.acc[3 * lane + 2]);
   } else {
+    const int pm_base = (lrow * S.W + x) * J.pm_batch - J.s_first;  // request slot of sample s: pm_base + s
     while (__any(alive)) {
-      if (alive) path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x);
+      if (alive)
+        path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x, nullptr,
+                                           &J.pm, pm_base);
     }
     result = L.acc;
   }
@@ -139,6 +144,28 @@ __global__ __launch_bounds__(256) void k_sum_chunks(const float* __restrict__ sl
     for (int c = 1; c < n_chunks; ++c) a += slab[(size_t)c * n + i];
     out[i] = a;
   }
+}
+
+// Photon-mapped trace(): total[i] += frame[i] + sum over the batch's samples of
+// w * (irradiance from the global map + irradiance from the caustic map)  (scene.go:313-319).
+// Requests that were never written (NaN position) contribute nothing.  Fixed order: reproducible.
+__global__ __launch_bounds__(256) void k_pm_accumulate(const float* __restrict__ frame, const float* __restrict__ qpos,
+                                                       const float* __restrict__ qw, const float* __restrict__ irr_g,
+                                                       const float* __restrict__ irr_c, int batch, size_t n_pixels,
+                                                       float* __restrict__ total, int first_batch) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  float r = frame[3 * i], g = frame[3 * i + 1], b = frame[3 * i + 2];
+  for (int s = 0; s < batch; ++s) {
+    const size_t q = 3 * (i * (size_t)batch + (size_t)s);
+    if (qpos[q] == qpos[q]) {
+      r = fmaf(qw[q], irr_g[q] + irr_c[q], r);
+      g = fmaf(qw[q + 1], irr_g[q + 1] + irr_c[q + 1], g);
+      b = fmaf(qw[q + 2], irr_g[q + 2] + irr_c[q + 2], b);
+    }
+  }
+  if (first_batch) total[3 * i] = r, total[3 * i + 1] = g, total[3 * i + 2] = b;
+  else total[3 * i] += r, total[3 * i + 1] += g, total[3 * i + 2] += b;
 }
 
 // scene.go:98-99 + WriteColor (scene.go:67-74): c = sum/samples; Gamma(2) = sqrt; Clamp =

@@ -864,6 +864,14 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
   for (int qi = q0; qi < q1; ++qi) {
     const float qx = nqx, qy = nqy, qz = nqz;
     if (qi + 1 < q1) nqx = qpos[3 * (size_t)qi + 3], nqy = qpos[3 * (size_t)qi + 4], nqz = qpos[3 * (size_t)qi + 5];
+    if (!(qx == qx)) {  // NaN position = no query in this slot (photon-mapped render): zero, and no bound to hand on
+      if (lane == 0) {
+        irrad[3 * (size_t)qi] = 0.0f, irrad[3 * (size_t)qi + 1] = 0.0f, irrad[3 * (size_t)qi + 2] = 0.0f;
+        if (rk2_out) rk2_out[qi] = -1.0f;
+      }
+      prev_rk = -1.0f;
+      continue;
+    }
     float bound = radius > 0.0f ? radius2 : INFINITY;  // photons beyond the radius never count (:141)
     bool tight = false;                                // the bound encloses k photons
     if (prev_rk >= 0.0f) {
@@ -1159,4 +1167,107 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
   } while (0);
   (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out);
   return rc;
+}
+
+// ---- photon-mapped trace() (scene.go:308-320, commented out in the reference) -----------------
+// trace() with the photon block enabled: a path that ends on a plain diffuse surface adds, besides
+// the direct light, m.Color * (caustic.IrradianceEst(p,n,1,100) + global.IrradianceEst(p,n,0,100)) / pi.
+// Wavefront form: samples are rendered in batches; the path-trace launch leaves one gather request
+// per (pixel, sample) that ended on a diffuse surface, k_gather_knn serves them for both maps, and
+// k_pm_accumulate adds weight * irradiance to the frame in a fixed order.
+#define GRT_PM_BATCH 8
+#define GRT_PM_K 100          // scene.go:313,316
+#define GRT_PM_CAUSTIC_R 1.0f // scene.go:313
+
+static int pm_batch_of(int samples) { return std::min(samples, GRT_PM_BATCH); }
+
+GRT_API uint64_t grt_render_pm_workspace_bytes(const grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards,
+                                               int32_t samples) {
+  if (!s || samples <= 0) return 0;
+  const int B = pm_batch_of(samples);
+  const uint64_t npix = (uint64_t)grt_shard_rows(grt_scene_desc_of(s)->height, shard, n_shards) * (uint64_t)grt_scene_desc_of(s)->width;
+  const uint64_t slabs = (grt_accum_workspace_bytes(s, o, shard, n_shards, B) + 255) & ~(uint64_t)255;
+  return slabs + npix * 3 * sizeof(float) + 5 * npix * (uint64_t)B * 3 * sizeof(float) + 1024;
+}
+
+GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int32_t shard,
+                                    int32_t n_shards, int32_t samples, float* d_rgb_sum, void* d_workspace,
+                                    uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
+  if (!s || !gmap || !cmap || !d_rgb_sum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: bad argument");
+  const uint64_t need = grt_render_pm_workspace_bytes(s, o, shard, n_shards, samples);
+  if (!d_workspace || workspace_bytes < need)
+    return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: workspace %llu bytes, need %llu", (unsigned long long)workspace_bytes,
+                    (unsigned long long)need);
+  const int B = pm_batch_of(samples);
+  const int W = grt_scene_desc_of(s)->width;
+  const size_t npix = (size_t)grt_shard_rows(grt_scene_desc_of(s)->height, shard, n_shards) * (size_t)W;
+  if (npix == 0) return GRT_OK;
+  const uint64_t slab_bytes = (grt_accum_workspace_bytes(s, o, shard, n_shards, B) + 255) & ~(uint64_t)255;
+  char* base = (char*)d_workspace;
+  float* frame = (float*)(base + slab_bytes);
+  float* qpos = frame + npix * 3;
+  const size_t nq = npix * (size_t)B;
+  float *qnrm = qpos + nq * 3, *qw = qnrm + nq * 3, *irr_g = qw + nq * 3, *irr_c = irr_g + nq * 3;
+  hipStream_t st = (hipStream_t)stream;
+  if (nq > (size_t)0x7fffffff) return grt_fail(GRT_ELIMIT, "grt_render_accum_pm_dev: %zu gather requests per batch", nq);
+  for (int s0 = 0, first = 1; s0 < samples; s0 += B, first = 0) {
+    const int b = std::min(B, samples - s0);
+    GRT_HIP(hipMemsetAsync(qpos, 0xff, nq * 3 * sizeof(float), st));  // all bits set = NaN = no request
+    int rc = grt_render_dev_internal(s, o, shard, n_shards, s0, b, frame, base, slab_bytes, d_ray_count, stream, qpos, qnrm, qw, B);
+    if (rc) return rc;
+    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, GRT_PM_K, irr_g, nullptr, st);  // scene.go:316
+    if (rc) return rc;
+    rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st);  // scene.go:313
+    if (rc) return rc;
+    rc = grt_pm_accumulate_internal(frame, qpos, qw, irr_g, irr_c, B, npix, d_rgb_sum, first, stream);
+    if (rc) return rc;
+  }
+  return GRT_OK;
+}
+
+// Host-buffer form on one device: linear RGB sums [H*W*3] (rgb_sum) and / or tone-mapped B,G,R bytes (pixels).
+static int render_pm_host(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int samples, float* rgb_sum,
+                          uint8_t* pixels, int pitch) {
+  if (!s || !gmap || !cmap || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_pm: bad argument");
+  if (o && o->n_devices > 1) return grt_fail(GRT_ELIMIT, "grt_render_pm: one device per call (shard with grt_render_accum_pm_dev)");
+  int dev;
+  int rc = pick_device(o, &dev);
+  if (rc) return rc;
+  const int W = grt_scene_desc_of(s)->width, H = grt_scene_desc_of(s)->height;
+  const size_t nfl = (size_t)W * H * 3;
+  const uint64_t ws_bytes = grt_render_pm_workspace_bytes(s, o, 0, 1, samples);
+  float* d_sum = nullptr;
+  void* d_ws = nullptr;
+  uint8_t* d_bgr = nullptr;
+  rc = GRT_OK;
+  do {
+    PTRY(hipMalloc(&d_sum, nfl * sizeof(float)));
+    PTRY(hipMalloc(&d_ws, ws_bytes));
+    rc = grt_render_accum_pm_dev(s, o, gmap, cmap, 0, 1, samples, d_sum, d_ws, ws_bytes, nullptr, nullptr);
+    if (rc) break;
+    if (rgb_sum) PTRY(hipMemcpy(rgb_sum, d_sum, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    if (pixels) {
+      const int bpp = pitch / W;
+      std::vector<uint8_t> h((size_t)W * H * 3);
+      PTRY(hipMalloc(&d_bgr, h.size()));
+      rc = grt_tonemap_dev(d_sum, W, H, samples, d_bgr, W * 3, nullptr);
+      if (rc) break;
+      PTRY(hipMemcpy(h.data(), d_bgr, h.size(), hipMemcpyDeviceToHost));
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+          for (int c = 0; c < 3; ++c) pixels[(size_t)y * pitch + (size_t)x * bpp + c] = h[((size_t)y * W + x) * 3 + c];
+    }
+  } while (0);
+  (void)hipFree(d_sum), (void)hipFree(d_ws), (void)hipFree(d_bgr);
+  return rc;
+}
+GRT_API int grt_render_pm(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, uint8_t* pixels, int32_t pitch,
+                          int32_t samples) {
+  if (!pixels || !s || pitch / grt_scene_desc_of(s)->width < 3) return grt_fail(GRT_EINVAL, "grt_render_pm: NULL pixels or pitch too small");
+  return render_pm_host(s, o, gmap, cmap, samples, nullptr, pixels, pitch);
+}
+GRT_API int grt_render_accum_pm(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, float* rgb_sum,
+                                int32_t samples) {
+  if (!rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_pm: NULL output");
+  return render_pm_host(s, o, gmap, cmap, samples, rgb_sum, nullptr, 0);
 }

@@ -266,6 +266,23 @@ class Scene:
         check(self._lib.grt_render_accum(self.handle, C.byref(o), _ptr(out), samples))
         return out
 
+    def RenderPhotonMapped(self, pixels, pitch, samples, seed=None):
+        """Render with the photon block of trace() enabled (scene.go:308-320): needs
+        self.globalPmap and self.causticPmap built (scene.go:22-23, mapPhotons scene.go:140-165)."""
+        buf = np.frombuffer(pixels, dtype=np.uint8) if not isinstance(pixels, np.ndarray) else pixels
+        if buf.size < self.H * pitch:
+            raise ValueError("pixels buffer smaller than H*pitch")
+        o = self.opts(seed)
+        check(self._lib.grt_render_pm(self.handle, C.byref(o), self.globalPmap.handle, self.causticPmap.handle, _ptr(buf),
+                                      pitch, samples))
+
+    def RenderAccumPhotonMapped(self, samples, seed=None):
+        out = np.empty((self.H, self.W, 3), np.float32)
+        o = self.opts(seed)
+        check(self._lib.grt_render_accum_pm(self.handle, C.byref(o), self.globalPmap.handle, self.causticPmap.handle,
+                                            _ptr(out), samples))
+        return out
+
     def TraceSamples(self, pixel_xy, samples, seed=None):
         xy = np.ascontiguousarray(pixel_xy, np.int32).reshape(-1, 2)
         rgb = np.empty((xy.shape[0], samples, 3), np.float32)

@@ -240,6 +240,25 @@ int grt_photon_gather_dev(const grt_pmap* pmap, const float* d_pos_xyz, const fl
 uint64_t grt_photon_gather_workspace_bytes(int32_t n);
 void grt_photon_free(grt_pmap* pmap);
 
+/* ---- photon-mapped trace() ------------------------------------------------------------ */
+
+/* Scene.Render with the photon block of trace() enabled (scene.go:308-320, commented out in
+ * the reference; scene.globalPmap / causticPmap, scene.go:22-23): a path that ends on a plain
+ * diffuse surface adds m.Color * (caustic.IrradianceEst(p,n,1,100) + global.IrradianceEst(p,n,
+ * 0,100)) / pi to the direct light of scene.go:322-346.  Same buffers as grt_render /
+ * grt_render_accum / grt_render_accum_dev (the _dev form also needs
+ * grt_render_pm_workspace_bytes() of workspace).  One device per call; linear-scan scenes. */
+int grt_render_pm(grt_scene* scene, const grt_opts* opts, const grt_pmap* global_map,
+                  const grt_pmap* caustic_map, uint8_t* pixels, int32_t pitch, int32_t samples);
+int grt_render_accum_pm(grt_scene* scene, const grt_opts* opts, const grt_pmap* global_map,
+                        const grt_pmap* caustic_map, float* rgb_sum, int32_t samples);
+int grt_render_accum_pm_dev(grt_scene* scene, const grt_opts* opts, const grt_pmap* global_map,
+                            const grt_pmap* caustic_map, int32_t shard, int32_t n_shards,
+                            int32_t samples, float* d_rgb_sum, void* d_workspace,
+                            uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream);
+uint64_t grt_render_pm_workspace_bytes(const grt_scene* scene, const grt_opts* opts, int32_t shard,
+                                       int32_t n_shards, int32_t samples);
+
 /* ---- misc ----------------------------------------------------------------------------- */
 
 /* Uniform in [0,1) with 24 random bits: draw `dim` of sample `sample` of pixel `pixel`

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "grto_scene_create": (C.c_int, [P(_capi.SceneDesc), P(_capi.PrimRec), C.c_int32,
                                     P(_capi.MaterialRec), C.c_int32, P(_vp)]),
     "grto_scene_destroy": (None, [_vp]),
+    "grto_scene_set_pmaps": (None, [_vp, _vp, _vp]),
     "grto_intersect": (C.c_int, [_vp, _d3, _d3, P(C.c_double)]),
     "grto_reflect": (None, [_d3, _d3, _d3]),
     "grto_refract": (C.c_int, [_d3, _d3, C.c_double, C.c_double, _d3]),
@@ -97,6 +98,12 @@ class OracleScene:
         if getattr(self, "handle", None):
             self.lib.grto_scene_destroy(self.handle)
             self.handle = None
+
+    def SetPhotonMaps(self, global_map, caustic_map):
+        """Enable the photon block of trace() (scene.go:308-320) with two OraclePhotonMap (None, None disables)."""
+        self._pmaps = (global_map, caustic_map)  # keep them alive
+        self.lib.grto_scene_set_pmaps(self.handle, global_map.handle if global_map else None,
+                                      caustic_map.handle if caustic_map else None)
 
     def Render(self, pixels, pitch, samples, seed=1, nthreads=0):
         rc = self.lib.grto_render(self.handle, seed, _ptr(pixels), pitch, samples, nthreads)

@@ -240,8 +240,19 @@ struct grto_scene {
   int32_t* tobjects; /* indices of Transparent objects (scene.go:48-50) */
   int32_t n_tobjects;
   double light_area;
+  /* scene.globalPmap / scene.causticPmap (scene.go:22-23); NULL = the photon block of trace()
+   * stays commented out as in the reference (scene.go:308-320) */
+  const struct grto_pmap* global_pmap;
+  const struct grto_pmap* caustic_pmap;
 };
 typedef struct grto_scene grto_scene;
+static void irradiance_est(const struct grto_pmap* m, const double* pos, const double* nrm, double radius, int k, int brute,
+                           double* out);
+/* Enables the photon-mapping block of trace() (scene.go:308-320) with these two maps. */
+GRTO_API void grto_scene_set_pmaps(grto_scene* s, const struct grto_pmap* global_map, const struct grto_pmap* caustic_map) {
+  s->global_pmap = global_map;
+  s->caustic_pmap = caustic_map;
+}
 
 GRTO_API int grto_scene_create(const grt_scene_desc* desc, const grt_prim* prims, int32_t n_prims,
                                const grt_material* mats, int32_t n_mats, grto_scene** out) {
@@ -406,7 +417,18 @@ static v3 trace(const grto_scene* s, ray r, int depth, pathctx* px) {
     if (!ok) dir = reflect(incident, n);
     ray r2 = {p, dir};
     result = v_plus(result, trace(s, r2, depth + 1, px));
-  } else { /* direct illumination, :322-346 */
+  } else {
+    if (s->global_pmap && s->caustic_pmap) { /* photon mapping, :308-320 (commented out in the reference) */
+      const double BRDF = 1 / M_PI;
+      double pp[3], nn[3], c[3], g[3];
+      to3(pp, p);
+      to3(nn, n);
+      irradiance_est(s->caustic_pmap, pp, nn, 1, 100, 0, c); /* :313 */
+      irradiance_est(s->global_pmap, pp, nn, 0, 100, 0, g);  /* :316 */
+      v3 irrad = v_plus(v_scale(from3(c), BRDF), v_scale(from3(g), BRDF));
+      result = v_plus(result, v_times(irrad, mc)); /* :318-319 */
+    }
+    /* direct illumination, :322-346 */
     for (int li = 0; li < s->n_lights; li++) {
       const grt_prim* l = &s->prims[s->lights[li]];
       v3 pos = prim_pos(l);

@@ -169,3 +169,32 @@ def test_sharded_build_equals_single_gpu_build(pkg, caustics, n):
     p, w, t = three.read()
     assert three.count() == n and three.emitted() == ref.emitted()
     assert (p == rp).all() and (w == rw).all() and (t == rt).all()
+
+
+def test_photon_mapped_trace_matches_oracle(pkg, ob):
+    """trace() with the photon block enabled (scene.go:308-320): GPU wavefront form (requests per
+    (pixel, sample), two gathers, fixed-order accumulation) against the oracle's recursive trace()
+    with the same photons and the same RNG streams."""
+    W, H, S = 64, 48, 12                                   # 12 = one full batch of 8 + a partial one
+    scene = pkg.scenes.cornell(W, H, "cornell8d")
+    scene.globalPmap = pkg.tracer.PhotonMap(60000).build(scene, caustics=False, seed=1)
+    scene.causticPmap = pkg.tracer.PhotonMap(8000).build(scene, caustics=True, seed=1)
+    ref = ob.OracleScene(scene.flat)
+    maps = []
+    for m in (scene.globalPmap, scene.causticPmap):
+        p, w, t = m.read()
+        maps.append(ob.OraclePhotonMap.load(p.astype(np.float64), w.astype(np.float64), t))
+    plain = scene.RenderAccum(S, seed=4).astype(np.float64) / S
+    a = scene.RenderAccumPhotonMapped(S, seed=4).astype(np.float64) / S
+    ref.SetPhotonMaps(*maps)
+    b = ref.RenderAccum(S, seed=4) / S
+    assert (a >= plain - 1e-6).all() and (a - plain).mean() > 0.002      # the photon term adds light
+    close = np.isclose(a, b, rtol=5e-3, atol=1e-4).all(-1)
+    print(f"photon-mapped: pixels within 5e-3 of the oracle {close.mean():.4f}, mean {a.mean((0,1))} vs {b.mean((0,1))}")
+    assert close.mean() > 0.97                                           # rest: FP32 path divergence at ties, k-th place swaps
+    assert np.allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=5e-3)
+    px = np.zeros(H * W * 4, np.uint8)
+    scene.RenderPhotonMapped(px, 4 * W, S, seed=4)
+    img = px.reshape(H, W, 4)[..., 2::-1].astype(np.float64)             # B,G,R -> R,G,B
+    want = np.floor(255.99 * np.minimum(1.0, np.sqrt(a)))
+    assert (np.abs(img - want) <= 1).mean() > 0.999

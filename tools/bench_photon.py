@@ -22,6 +22,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--cpu-queries", type=int, default=20000)
+ap.add_argument("--render-spp", type=int, default=16, help="photon-mapped trace() (scene.go:308-320) at this spp; 0 = skip")
 a = ap.parse_args()
 W, H = a.width, a.height
 lib = pkg._capi.load()
@@ -80,6 +81,26 @@ if a.cpu_queries > 0:
     dt = time.perf_counter() - t0
     cpu = {"queries_per_s": len(sel) / dt, "cores": threads, "kind": "port", "sample": f"{len(sel)} of the {nq} queries, k={a.k}"}
 
+pm = None
+if a.render_spp > 0:
+    o = scene.opts(seed=1)
+    nbytes = int(lib.grt_render_pm_workspace_bytes(scene.handle, C.byref(o), 0, 1, a.render_spp))
+    wsp = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    tt = []
+    for r in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pkg._capi.check(lib.grt_render_accum_pm_dev(scene.handle, C.byref(o), gmap.handle, cmap.handle, 0, 1, a.render_spp,
+                                                    frame.data_ptr(), wsp.data_ptr(), nbytes, None, stream))
+        e1.record()
+        torch.cuda.synchronize()
+        tt.append(e0.elapsed_time(e1))
+    tt.sort()
+    pm = {"spp": a.render_spp, "ms": tt[1], "Msamples_per_s": W * H * a.render_spp / tt[1] / 1e3,
+          "mean_radiance": (frame.mean((0, 1)) / a.render_spp).tolist(),
+          "note": "path trace + one gather request per path that ends on a diffuse surface x 2 maps (k=100; radius 0 / 1) + accumulate"}
+
 print(json.dumps({
     "workload": f"C4: cornell8d, {a.photons} global + {a.photons // 2} caustic photons, k={a.k}, {nq} primary-hit queries at {W}x{H}",
     "emission": {"global_s": t_global, "global_emitted": gmap.emitted(), "global_stored": gmap.count(),
@@ -87,4 +108,4 @@ print(json.dumps({
                  "global_stored_per_s": gmap.count() / t_global, "caustic_emitted_per_s": cmap.emitted() / t_caustic,
                  "note": "wall time of grt_photon_build (synchronous): emission + scan/scatter batches, then the device tree build "
                          "(one radix sort per level); photons never leave the device"},
-    "gather": res, "cpu_baseline": cpu}))
+    "gather": res, "photon_mapped_render": pm, "cpu_baseline": cpu}))
