@@ -835,7 +835,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
                                                                   const float* __restrict__ qnrm, int n_q, int q_per_wave,
                                                                   float radius, int k, float* __restrict__ irrad,
                                                                   float* __restrict__ rk2_out,
-                                                                  unsigned long long* __restrict__ stats) {
+                                                                  unsigned long long* __restrict__ stats, float loose) {
   constexpr int CAP = 64 * RMAX;
   __shared__ float4 top_lo[GATHER_LDS_BOXES], top_hi[GATHER_LDS_BOXES];
   __shared__ float pool_d2[GATHER_WAVES][CAP];
@@ -878,7 +878,9 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
       const float dx = qx - pqx, dy = qy - pqy, dz = qz - pqz;
       const float r = prev_rk + sqrt32(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
       const float b = r * r * 1.0001f;
-      if (b < bound) bound = b, tight = true;
+      // a bound far above the previous k-th distance (queries further apart than r_k) still culls, but is
+      // worth tightening as soon as k photons are in the pool
+      if (b < bound) bound = b, tight = b <= loose * prev_rk * prev_rk;
     }
     int count = 0;
     uint32_t vb[RMAX];
@@ -919,6 +921,14 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
       count += popc64(m);
       st_leaves++;
     };
+    // which pending child next: in index order under a tight bound, nearest box first otherwise (so that
+    // the pool reaches k photons, and the bound its final size, after as few buckets as possible)
+    auto pick_child = [&](unsigned long long pending, float d2b) -> int {
+      if (tight) return __builtin_ctzll(pending);
+      const bool in = (pending >> lane) & 1ull;
+      const uint32_t dmin = wave_total_min_u(in ? __float_as_uint(d2b) : 0xffffffffu);
+      return __builtin_ctzll(__builtin_amdgcn_ballot_w64(in & (__float_as_uint(d2b) == dmin)));
+    };
     auto load_pool = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -954,7 +964,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     };
 
     if (T.n > 0) {
-      if (!tight && radius == 0.0f) {
+      if (bound == INFINITY) {
         // No bound yet: nearest child first down to the nearest leaves until k photons are seen;
         // their largest distance bounds the k-th.  The pool is then emptied and the walk below
         // starts over with that bound.
@@ -999,8 +1009,8 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
         if (lvl == last) {  // the children are leaf buckets
           const int pb = prefix << (lvl == 0 ? T.b0 : KD_FAN_BITS);
           while (mask) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
+            const int l = pick_child(mask, d2box);
+            mask &= ~(1ull << l);
             append_leaf(pb | l, bound);
             if (count > CAP - 64) reselect(true);
             else if (!tight && count >= k) reselect(false);
@@ -1016,8 +1026,8 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(stk_lo, lvl);
           continue;
         }
-        const int l = __builtin_ctzll(mask);
-        mask &= mask - 1;
+        const int l = pick_child(mask, d2box);  // (a mask popped from the stack has lost its distances: index order)
+        mask &= ~(1ull << l);
         const bool me = lane == lvl;
         stk_lo = me ? (int)(uint32_t)mask : stk_lo;
         stk_hi = me ? (int)(uint32_t)(mask >> 32) : stk_hi;
@@ -1108,7 +1118,9 @@ static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_
   // waves per workgroup by pool size, so that the LDS pools of a CU's 32 waves fit in 160 KB
 #define GRT_GATHER_LAUNCH(RMAX, WAVES)                                                                               \
   hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, \
-                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats)
+                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats, loose)
+  const char* lenv = getenv("GRT_GATHER_LOOSE");  // tuning: carried bound / previous r_k^2 above which the bound counts as loose
+  const float loose = lenv ? (float)atof(lenv) : 1.6f;
   const char* wenv = getenv("GRT_GATHER_WAVES");  // tuning: waves per workgroup of the k <= 128 kernel
   const int wsel = wenv ? atoi(wenv) : 16;
   if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4);
