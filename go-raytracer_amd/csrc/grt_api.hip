@@ -131,6 +131,7 @@ struct BvhBuild {
   std::vector<float4> nodes;
   std::atomic<int> n_nodes{0};
   int max_depth = 0;
+  int leaf = GRT_BVH_LEAF;       // objects per leaf (<= 7: the count lives in 3 bits of the reference)
   std::mutex mu;
 };
 static void bvh_range_box(const BvhBuild& B, int a, int b, float* lo, float* hi) {
@@ -144,7 +145,7 @@ static void bvh_range_box(const BvhBuild& B, int a, int b, float* lo, float* hi)
 // Returns the reference of the subtree over order[a, b) and its box.
 static int bvh_build(BvhBuild& B, int a, int b, float* lo, float* hi, int depth, int par_depth) {
   bvh_range_box(B, a, b, lo, hi);
-  if (b - a <= GRT_BVH_LEAF) {
+  if (b - a <= B.leaf) {
     std::lock_guard<std::mutex> g(B.mu);
     B.max_depth = std::max(B.max_depth, depth);
     return ~((a << 3) | (b - a));
@@ -202,7 +203,10 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   }
   B.nodes.resize(4 * (size_t)std::max(1, n));
   float lo[3], hi[3];
-  if (n <= GRT_BVH_LEAF) {  // a single leaf still needs a root node: the second child is empty
+  // Leaves of 2 objects walk fastest (measured at C5); deeper scenes take larger leaves so that the
+  // balanced tree fits the per-lane traversal stack.
+  while (B.leaf < 7 && (((long long)B.leaf << (GRT_BVH_STACK - 2)) < (long long)n)) B.leaf = B.leaf == 2 ? 4 : 7;
+  if (n <= B.leaf) {  // a single leaf still needs a root node: the second child is empty
     bvh_range_box(B, 0, n, lo, hi);
     B.n_nodes = 1;
     B.nodes[0] = make_float4(lo[0], lo[1], lo[2], __builtin_bit_cast(float, ~((0 << 3) | n)));

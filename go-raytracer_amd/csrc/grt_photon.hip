@@ -1098,15 +1098,17 @@ GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (
 
 // Queries served back to back by one wave (they share the carried bound).  GRT_GATHER_QPW
 // overrides the default for tuning runs (tools/bench_photon.py).
-static int gather_qpw() {
+static int gather_qpw(float radius) {
   const char* e = getenv("GRT_GATHER_QPW");
   const int v = e ? atoi(e) : 0;
-  return v > 0 ? v : 16;
+  // measured at C4: 24 for the unbounded search (longer runs share the carried bound), 8 with a radius
+  // (queries near the caustic cost far more than the rest: shorter runs balance the waves)
+  return v > 0 ? v : (radius > 0.0f ? 8 : 24);
 }
 
 static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
                          float* d_rk2, hipStream_t st) {
-  const int qpw = gather_qpw();
+  const int qpw = gather_qpw(radius);
   KdView T = {pm->d_boxes, pm->d_pos3, pm->d_pwb, pm->d_lut, pm->n, pm->depth, pm->levels, pm->b0, pm->n_boxes};
   // GRT_GATHER_STATS=1 (tuning runs only): per-launch totals of node steps, leaf buckets read,
   // selections and pool sizes on stderr; allocates and synchronises, so never set in production.
