@@ -149,7 +149,9 @@ def main():
                                    f"{S} spp, depth cap 6, seed 1, path tracing",
                        "parallelism": f"tile-sharded, interleaved 8-row bands over {world} GPU(s), "
                                       "RCCL gather of finished bands to rank 0",
-                       "chunk_spp": args.chunk_spp or "auto"},
+                       "chunk_spp": args.chunk_spp or "auto",
+                       "culling": "8x8 tiles whose ray pyramid misses the scene's bounding box are not traced (their samples "
+                                  "are black either way and are counted in value; rays_* count executed intersect() calls)"},
             "rays_per_s": rays_per_s,
             "rays_per_sample": rays / samples_total,
             "roofline": {

@@ -113,6 +113,7 @@ GRT_API void grt_scene_destroy(grt_scene* s) {
     (void)hipFree(kv.second.bvh_nodes);
     (void)hipFree(kv.second.bvh_prims);
     (void)hipFree(kv.second.bvh_ids);
+    (void)hipFree(kv.second.tile_live);
   }
   if (have) (void)hipSetDevice(cur);
   delete s;
@@ -231,6 +232,66 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   return GRT_OK;
 }
 
+// ---- tile culling ------------------------------------------------------------------------
+// live[ty * tiles_x + tx] = 0 when the pyramid of camera rays through 8x8 tile (tx, ty) — all
+// jitters included: u in [x0/W, (x0+8)/W], v likewise (scene.go:93-94) — misses the bounding box of
+// all objects: one of the pyramid's four side planes (or the plane through the eye across the
+// tile's central ray) has the whole box on its outer side.  Ray directions inside the tile are convex
+// combinations of the four corner directions (Camera.Ray is affine in u and v, camera.go:37) and
+// the box is convex, so no ray of the tile reaches it.  Float64, with a margin of 1e-5 (sine of
+// an angle) that covers the FP32 ray generation of the kernels a hundred times over.
+static std::vector<uint8_t> cull_tiles(const grt_scene* s) {
+  const int W = s->d.width, H = s->d.height, tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+  std::vector<uint8_t> live((size_t)tiles_x * tiles_y, 1);
+  if (getenv("GRT_NO_CULL")) return live;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (const grt_prim& p : s->prims)
+    for (int c = 0; c < 3; ++c) {
+      const double a = p.kind == GRT_KIND_AABB ? std::min(p.a[c], p.b[c]) : p.a[c] - std::fabs(p.radius);
+      const double b = p.kind == GRT_KIND_AABB ? std::max(p.a[c], p.b[c]) : p.a[c] + std::fabs(p.radius);
+      lo[c] = std::min(lo[c], a), hi[c] = std::max(hi[c], b);
+    }
+  if (s->prims.empty()) {
+    std::fill(live.begin(), live.end(), 0);
+    return live;
+  }
+  for (int c = 0; c < 3; ++c)
+    if (!std::isfinite(lo[c]) || !std::isfinite(hi[c])) return live;  // no culling with non-finite geometry
+  const grt_camera& cam = s->d.cam;
+  double rel[8][3];  // box corners relative to the eye
+  for (int k = 0; k < 8; ++k)
+    for (int c = 0; c < 3; ++c) rel[k][c] = ((k >> c) & 1 ? hi[c] : lo[c]) - cam.origin[c];
+  auto dir = [&](double u, double v, double* d) {
+    for (int c = 0; c < 3; ++c) d[c] = cam.lower_left[c] + cam.horizontal[c] * u + cam.vertical[c] * v - cam.origin[c];
+  };
+  auto outside = [&](const double* m) {  // the whole box strictly on the negative side of the plane m.x = 0
+    const double mlen = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    if (!(mlen > 0.0)) return false;
+    for (int k = 0; k < 8; ++k) {
+      const double blen = std::sqrt(rel[k][0] * rel[k][0] + rel[k][1] * rel[k][1] + rel[k][2] * rel[k][2]);
+      if (!(m[0] * rel[k][0] + m[1] * rel[k][1] + m[2] * rel[k][2] < -1e-5 * mlen * blen)) return false;
+    }
+    return true;
+  };
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      const double u0 = (double)(8 * tx) / W, u1 = (double)(8 * tx + 8) / W, v0 = (double)(8 * ty) / H, v1 = (double)(8 * ty + 8) / H;
+      double d[4][3], dc[3];
+      dir(u0, v0, d[0]), dir(u1, v0, d[1]), dir(u1, v1, d[2]), dir(u0, v1, d[3]);
+      dir(0.5 * (u0 + u1), 0.5 * (v0 + v1), dc);
+      bool dead = outside(dc);  // the scene lies behind the eye as seen along this tile
+      for (int e = 0; e < 4 && !dead; ++e) {
+        const double* a = d[e];
+        const double* b = d[(e + 1) & 3];
+        double m[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        if (m[0] * dc[0] + m[1] * dc[1] + m[2] * dc[2] < 0.0) m[0] = -m[0], m[1] = -m[1], m[2] = -m[2];  // inside = positive
+        dead = outside(m);
+      }
+      live[(size_t)ty * tiles_x + tx] = dead ? 0 : 1;
+    }
+  return live;
+}
+
 // Stage the SoA copies on the current device (first use only).
 static int stage(grt_scene* s, DeviceScene& out) {
   int dev = 0;
@@ -294,6 +355,9 @@ static int stage(grt_scene* s, DeviceScene& out) {
     int rc = stage_bvh(s, hp, d);
     if (rc) return rc;
   }
+  const std::vector<uint8_t> live = cull_tiles(s);
+  GRT_HIP(hipMalloc(&d.tile_live, live.size()));
+  GRT_HIP(hipMemcpy(d.tile_live, live.data(), live.size(), hipMemcpyHostToDevice));
   s->dev[dev] = d;
   out = d;
   return GRT_OK;
@@ -320,6 +384,7 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
   k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_ids = d.bvh_ids;
+  k.tile_live = d.tile_live;
   *ks = k;
   return GRT_OK;
 }

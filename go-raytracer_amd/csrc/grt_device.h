@@ -86,6 +86,9 @@ struct KScene {
   const float4* __restrict__ bvh_nodes;
   const float4* __restrict__ bvh_prims;
   const int* __restrict__ bvh_ids;
+  // tile_live[ty * tiles_x + tx] == 0: no camera ray through 8x8 tile (tx, ty) can reach the scene's
+  // bounding box (frustum-plane test in float64 on the host, grt_api.hip); its pixels are black
+  const uint8_t* __restrict__ tile_live;
 };
 
 #define GRT_MAT_TRANSPARENT 1

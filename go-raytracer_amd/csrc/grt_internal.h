@@ -31,6 +31,7 @@ struct DeviceScene {
   float4* bvh_nodes = nullptr;  // grt_bvh.h; NULL for linear-scan scenes
   float4* bvh_prims = nullptr;
   int* bvh_ids = nullptr;
+  uint8_t* tile_live = nullptr;  // per 8x8 tile of the frame: can a camera ray reach the scene bounds?
 };
 
 struct grt_scene {

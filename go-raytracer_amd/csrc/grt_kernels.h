@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
 
   int n_rays = 0;
   bool alive = valid & (s0 < s_end);
+  // A tile whose rays all pass the scene's bounding box by: every sample is a miss (black,
+  // scene.go:244-250) and no intersect() call is made for it.
+  const bool culled = S.tile_live && !S.tile_live[(J.shard + lband * J.n_shards) * J.tiles_x + tx];  // wave-uniform
+  if (culled) alive = false;
   LaneState L;
   lane_begin(S, fx, fy, pix_key, s0, L);
   f3 result;
@@ -103,9 +107,9 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     Q.acc[3 * lane] = 0.0f, Q.acc[3 * lane + 1] = 0.0f, Q.acc[3 * lane + 2] = 0.0f;
     qkey[64 * w + lane] = pix_key;
     Q.s0 = s0, Q.x0 = tx * 8, Q.y0 = (J.shard + lband * J.n_shards) * 8;
-    Q.next = 64, Q.qend = 64 * (s_end - s0);
+    Q.next = 64, Q.qend = culled ? 0 : 64 * (s_end - s0);
     L.pix = lane;
-    alive = s0 < s_end;
+    alive = (s0 < s_end) & !culled;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     while (__any(alive)) {
       if (alive)

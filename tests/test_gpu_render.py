@@ -137,3 +137,27 @@ def test_sample_range_frames_add_up(pkg):
         rays += int(ren.ray_count.item())
     assert torch.allclose(total, full, rtol=1e-5, atol=1e-6)
     assert rays == scene.last_ray_count()
+
+
+def test_tile_culling_changes_no_pixel(pkg, monkeypatch):
+    """Tiles whose ray pyramid misses the scene's bounding box are skipped (grt_api.hip cull_tiles):
+    the frame is bit-identical to the one rendered with every tile traced, at 16:9 (wide black
+    borders), 1:1 and an odd size, and fewer intersect() calls are executed."""
+    for (w, h) in ((320, 180), (128, 128), (203, 77)):
+        cam = pkg.scenes.cornell_camera(w / h)
+        a = pkg.tracer.NewScene(w, h, cam, pkg.scenes.cornell_objects())
+        fa = a.RenderAccum(8, seed=6)
+        ra = a.last_ray_count()
+        monkeypatch.setenv("GRT_NO_CULL", "1")            # read when a scene is first staged on a device
+        b = pkg.tracer.NewScene(w, h, cam, pkg.scenes.cornell_objects())
+        fb = b.RenderAccum(8, seed=6)
+        rb = b.last_ray_count()
+        monkeypatch.delenv("GRT_NO_CULL")
+        assert (fa == fb).all()
+        assert ra <= rb
+        if (w, h) == (320, 180):
+            assert ra < 0.9 * rb                           # the side borders of the 16:9 frame are culled
+    # a camera that looks away from the scene: everything is culled, the frame is black
+    T = pkg.tracer
+    away = T.NewScene(64, 64, T.NewCamera(pkg.scenes.EYE, (278.0, 278.0, -2000.0), pkg.scenes.VUP, 40.0, 1.0), pkg.scenes.cornell_objects())
+    assert (away.RenderAccum(4, seed=1) == 0).all() and away.last_ray_count() == 0
