@@ -445,6 +445,11 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->s_first = 0;
   j->pm.pos = j->pm.nrm = j->pm.w = nullptr;
   j->pm_batch = 0;
+  static const int shade_min = [] {
+    const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 0 = lockstep levels
+    return e ? std::max(0, std::min(64, atoi(e))) : 1;
+  }();
+  j->shade_min = shade_min;
   return GRT_OK;
 }
 

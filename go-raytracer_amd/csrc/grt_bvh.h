@@ -79,54 +79,72 @@ GRT_DEV void bvh_object(float4 pa, float4 pb, int id, const Ray32& r, float bias
   }
 }
 
-// stack: this lane's column of the LDS stack, entry d at stack[d * stride].
+// A walk that can be suspended between rounds: the reference in hand, the stack height (the stack
+// itself is the lane's column of the LDS stack, entry d at stack[d * stride]) and the hit so far.
+struct BvhWalk {
+  int ref, sp;
+  BvhHit H;
+};
+GRT_DEV void bvh_walk_begin(BvhWalk& w) {
+  w.H.tbest = 3.402823466e38f, w.H.best = -1, w.H.qt = 0.0f, w.H.qbest = 0x7fffffff;
+  w.sp = 0;
+  w.ref = 0;  // the root is an inner node
+}
+GRT_DEV int bvh_walk_result(const BvhWalk& w, float& t_out) {
+  if (w.H.qbest != 0x7fffffff) {
+    t_out = w.H.qt;
+    return w.H.qbest;
+  }
+  t_out = w.H.tbest;
+  return w.H.best;
+}
+// One round for the lanes that call it (the walking lanes of the wave): inner nodes until every one
+// of them holds a leaf or has finished (lanes at a leaf wait), then the leaves.
+template <bool CAREFUL>
+GRT_DEV void bvh_walk_round(const float4* __restrict__ nodes, const float4* __restrict__ bprims, const int* __restrict__ bids,
+                            const Ray32& r, float bias, BvhWalk& w, int* stack, int stride) {
+  int ref = w.ref, sp = w.sp;
+  while (__any(ref >= 0 && ref != GRT_BVH_DONE)) {
+    if (ref >= 0 && ref != GRT_BVH_DONE) {
+      const float4 a0 = nodes[4 * (size_t)ref], a1 = nodes[4 * (size_t)ref + 1];
+      const float4 b0 = nodes[4 * (size_t)ref + 2], b1 = nodes[4 * (size_t)ref + 3];
+      float tn0, tn1;
+      const bool h0 = bvh_box<CAREFUL>(a0, a1, r, w.H.tbest, tn0);
+      const bool h1 = bvh_box<CAREFUL>(b0, b1, r, w.H.tbest, tn1);
+      const int r0 = __float_as_int(a0.w), r1 = __float_as_int(b0.w);
+      if (h0 & h1) {
+        const bool first0 = tn0 <= tn1;
+        stack[sp * stride] = first0 ? r1 : r0;
+        sp++;
+        ref = first0 ? r0 : r1;
+      } else if (h0 | h1) {
+        ref = h0 ? r0 : r1;
+      } else if (sp > 0) {
+        ref = stack[--sp * stride];
+      } else {
+        ref = GRT_BVH_DONE;
+      }
+    }
+  }
+  if (ref != GRT_BVH_DONE) {  // a leaf
+    const int first = (~ref) >> 3, cnt = (~ref) & 7;
+    for (int j = 0; j < cnt; ++j) {
+      const float4 pa = bprims[2 * (size_t)(first + j)], pb = bprims[2 * (size_t)(first + j) + 1];
+      bvh_object<CAREFUL>(pa, pb, bids[first + j], r, bias, w.H);
+    }
+    ref = sp > 0 ? stack[--sp * stride] : GRT_BVH_DONE;
+  }
+  w.ref = ref, w.sp = sp;
+}
+
 template <bool CAREFUL>
 GRT_DEV int intersect_bvh_t(const float4* __restrict__ nodes, const float4* __restrict__ bprims, const int* __restrict__ bids,
                             const Ray32& r, float bias, float& t_out, int* stack, int stride) {
-  BvhHit H;
-  H.tbest = 3.402823466e38f, H.best = -1, H.qt = 0.0f, H.qbest = 0x7fffffff;
-  int sp = 0;
-  int ref = 0;  // the root is an inner node
-  for (;;) {
-    // inner nodes until this lane holds a leaf or has nothing left; lanes at a leaf wait
-    while (__any(ref >= 0 && ref != GRT_BVH_DONE)) {
-      if (ref >= 0 && ref != GRT_BVH_DONE) {
-        const float4 a0 = nodes[4 * (size_t)ref], a1 = nodes[4 * (size_t)ref + 1];
-        const float4 b0 = nodes[4 * (size_t)ref + 2], b1 = nodes[4 * (size_t)ref + 3];
-        float tn0, tn1;
-        const bool h0 = bvh_box<CAREFUL>(a0, a1, r, H.tbest, tn0);
-        const bool h1 = bvh_box<CAREFUL>(b0, b1, r, H.tbest, tn1);
-        const int r0 = __float_as_int(a0.w), r1 = __float_as_int(b0.w);
-        if (h0 & h1) {
-          const bool first0 = tn0 <= tn1;
-          stack[sp * stride] = first0 ? r1 : r0;
-          sp++;
-          ref = first0 ? r0 : r1;
-        } else if (h0 | h1) {
-          ref = h0 ? r0 : r1;
-        } else if (sp > 0) {
-          ref = stack[--sp * stride];
-        } else {
-          ref = GRT_BVH_DONE;
-        }
-      }
-    }
-    if (!__any(ref != GRT_BVH_DONE)) break;
-    if (ref != GRT_BVH_DONE) {  // a leaf
-      const int first = (~ref) >> 3, cnt = (~ref) & 7;
-      for (int j = 0; j < cnt; ++j) {
-        const float4 pa = bprims[2 * (size_t)(first + j)], pb = bprims[2 * (size_t)(first + j) + 1];
-        bvh_object<CAREFUL>(pa, pb, bids[first + j], r, bias, H);
-      }
-      ref = sp > 0 ? stack[--sp * stride] : GRT_BVH_DONE;
-    }
-  }
-  if (H.qbest != 0x7fffffff) {
-    t_out = H.qt;
-    return H.qbest;
-  }
-  t_out = H.tbest;
-  return H.best;
+  BvhWalk w;
+  bvh_walk_begin(w);
+  while (__any(w.ref != GRT_BVH_DONE))
+    if (w.ref != GRT_BVH_DONE) bvh_walk_round<CAREFUL>(nodes, bprims, bids, r, bias, w, stack, stride);
+  return bvh_walk_result(w, t_out);
 }
 static_assert(GRT_BVH_LEAF <= 7, "a leaf reference holds its object count in 3 bits");
 // Measured alternative (C5, 16 spp): the same tree folded into 4-ary nodes (128 B, four slab tests and

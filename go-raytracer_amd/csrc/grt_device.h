@@ -457,6 +457,11 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
   L.depth = 1;
 }
 
+template <bool QUEUE>
+GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
+                        uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t,
+                        WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0);
+
 // One level of trace() for one lane.  NP > 0: tp (objects) and tm (materials) are LDS copies
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
 // arrays of S and the loop runs over S.n_prims.  `alive` turns false when the lane has finished
@@ -482,6 +487,15 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   else
     id = intersect32_t<false>(S, r, t);
   n_rays++;                                         // scene.go:242
+  path_shade<QUEUE>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base);
+}
+
+// Everything of one trace() level after intersect(): Surface, material dispatch, the radiance a
+// terminating level carries, and the lane's next ray (same path, or the next sample's primary ray).
+template <bool QUEUE>
+GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
+                        uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
+                        const PmOut* pm, int pm_base) {
   const bool hit = id >= 0;                         // scene.go:244
   const int idc = hit ? id : 0;
   const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];

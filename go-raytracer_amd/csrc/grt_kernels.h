@@ -21,6 +21,7 @@ struct RenderJob {
   int s_first;          // first sample index (sample-range sharding; 0 otherwise)
   PmOut pm;             // photon-mapped trace(): gather requests of this launch (pos == NULL: off)
   int pm_batch;         // samples per pixel the request arrays hold
+  int shade_min;        // hierarchy scenes: lanes that must wait for shading before the wave shades (0: every level in lockstep)
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -117,6 +118,42 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     result = mk3(Q.acc[3 * lane], Q.acc[3 * lane + 1], Q.acc[3 * lane + 2]);
+  } else if (NP < 0 && J.shade_min > 0) {
+    // Hierarchy scenes: walks differ a lot in length (C5: 20 % of the lanes active when every lane
+    // waits for the wave's longest walk before shading).  So a lane whose walk has ended WAITS, and
+    // the wave shades only once J.shade_min lanes wait or nobody walks; the others keep their walk
+    // (reference in hand, stack, hit so far) across the shading and go on afterwards.  Shading is
+    // ~10 % of a level's instructions, so running it at low occupancy of the lanes costs little and
+    // the walk rounds run with most lanes active.  Which lanes meet in a round depends only on the
+    // wave's own paths: the frame is reproducible and independent of sharding.
+    Ray32 r;
+    BvhWalk wk;
+    ray_setup_unit(r, L.O, L.D);
+    bvh_walk_begin(wk);
+    if (!alive) wk.ref = GRT_BVH_DONE;
+    int* stack = bvh_stack + threadIdx.x;
+    while (__any(alive)) {
+      for (;;) {
+        const bool walking = wk.ref != GRT_BVH_DONE;
+        if (!__any(walking)) break;
+        if (__builtin_popcountll(__ballot(alive & !walking)) >= J.shade_min) break;
+        if (walking) {
+          if (__any(ray_has_zero(r))) bvh_walk_round<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, wk, stack, 256);
+          else bvh_walk_round<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, wk, stack, 256);
+        }
+      }
+      if (alive & (wk.ref == GRT_BVH_DONE)) {
+        float t;
+        const int id = bvh_walk_result(wk, t);
+        n_rays++;
+        path_shade<false>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, r, id, t);
+        if (alive) {
+          ray_setup_unit(r, L.O, L.D);
+          bvh_walk_begin(wk);
+        }
+      }
+    }
+    result = L.acc;
   } else {
     const int pm_base = (lrow * S.W + x) * J.pm_batch - J.s_first;  // request slot of sample s: pm_base + s
     while (__any(alive)) {
