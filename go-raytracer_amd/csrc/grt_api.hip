@@ -112,7 +112,6 @@ GRT_API void grt_scene_destroy(grt_scene* s) {
     (void)hipFree(kv.second.prims64);
     (void)hipFree(kv.second.bvh_nodes);
     (void)hipFree(kv.second.bvh_prims);
-    (void)hipFree(kv.second.bvh_ids);
     (void)hipFree(kv.second.tile_live);
   }
   if (have) (void)hipSetDevice(cur);
@@ -220,15 +219,50 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     if (B.max_depth + 1 > GRT_BVH_STACK)
       return grt_fail(GRT_ELIMIT, "grt_scene: hierarchy depth %d exceeds the traversal stack (%d)", B.max_depth, GRT_BVH_STACK);
   }
+  // leaf-order object records; the last word becomes index << 1 | is_box (grt_bvh.h)
   std::vector<float4> bp(2 * (size_t)n);
-  for (int i = 0; i < n; ++i) bp[2 * (size_t)i] = hp[2 * (size_t)B.order[i]], bp[2 * (size_t)i + 1] = hp[2 * (size_t)B.order[i] + 1];
-  const size_t nn = 4 * (size_t)B.n_nodes.load();
-  GRT_HIP(hipMalloc(&d.bvh_nodes, nn * sizeof(float4)));
+  for (int i = 0; i < n; ++i) {
+    const int o = B.order[i];
+    float4 pb = hp[2 * (size_t)o + 1];
+    pb.w = __builtin_bit_cast(float, (uint32_t)o << 1 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 1u));
+    bp[2 * (size_t)i] = hp[2 * (size_t)o], bp[2 * (size_t)i + 1] = pb;
+  }
+  // The 16-bit grid: the scene's bounds widened by 1/1024 on each side, 65535 cells per axis.  Boxes
+  // round outward and take one more cell, which covers the FP32 rounding of the slab arithmetic in
+  // grid coordinates (< 0.01 cell: coordinates <= 65535 at 2^-24 relative).
+  bvh_range_box(B, 0, n, lo, hi);
+  float gmin[3], gs[3];
+  for (int c = 0; c < 3; ++c) {
+    const double ext = std::max((double)hi[c] - (double)lo[c], 1e-30 + 1e-6 * (std::fabs((double)hi[c]) + std::fabs((double)lo[c])));
+    gmin[c] = (float)((double)lo[c] - ext / 1024.0);
+    gs[c] = (float)(ext * (1.0 + 2.0 / 1024.0) / 65535.0);
+    d.bvh_grid[c] = gmin[c], d.bvh_grid[3 + c] = gs[c], d.bvh_grid[6 + c] = 1.0f / gs[c];
+  }
+  d.bvh_depth = B.max_depth;
+  const size_t n_nodes = (size_t)B.n_nodes.load();
+  std::vector<uint4> qn(2 * n_nodes);
+  bool grid_ok = true;
+  for (size_t k = 0; k < 2 * n_nodes; ++k) {
+    const float4 l = B.nodes[2 * k], h = B.nodes[2 * k + 1];
+    const float fl[3] = {l.x, l.y, l.z}, fh[3] = {h.x, h.y, h.z};
+    uint32_t ql[3], qh[3];
+    for (int c = 0; c < 3; ++c) {
+      if (fl[c] > fh[c]) {  // the empty second child of a single-leaf tree (a leaf of 0 objects)
+        ql[c] = 0, qh[c] = 0;
+        continue;
+      }
+      const double a = std::floor(((double)fl[c] - (double)gmin[c]) / (double)gs[c]) - 1.0;
+      const double b = std::ceil(((double)fh[c] - (double)gmin[c]) / (double)gs[c]) + 1.0;
+      if (a < 0.0 || b > 65535.0) grid_ok = false;
+      ql[c] = (uint32_t)std::max(0.0, a), qh[c] = (uint32_t)std::min(65535.0, b);
+    }
+    qn[k] = make_uint4(ql[0] | ql[1] << 16, ql[2] | qh[0] << 16, qh[1] | qh[2] << 16, (uint32_t)__builtin_bit_cast(int, l.w));
+  }
+  if (!grid_ok) return grt_fail(GRT_EINVAL, "internal: hierarchy box outside its grid");
+  GRT_HIP(hipMalloc(&d.bvh_nodes, qn.size() * sizeof(uint4)));
   GRT_HIP(hipMalloc(&d.bvh_prims, bp.size() * sizeof(float4)));
-  GRT_HIP(hipMalloc(&d.bvh_ids, (size_t)n * sizeof(int)));
-  GRT_HIP(hipMemcpy(d.bvh_nodes, B.nodes.data(), nn * sizeof(float4), hipMemcpyHostToDevice));
+  GRT_HIP(hipMemcpy(d.bvh_nodes, qn.data(), qn.size() * sizeof(uint4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(d.bvh_prims, bp.data(), bp.size() * sizeof(float4), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(d.bvh_ids, B.order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
   return GRT_OK;
 }
 
@@ -383,7 +417,10 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
   for (size_t i = 0; i < s->prims.size() && i < 32; ++i)
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
-  k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_ids = d.bvh_ids;
+  k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_depth = d.bvh_depth;
+  k.bvh_grid.gmin = {d.bvh_grid[0], d.bvh_grid[1], d.bvh_grid[2]};
+  k.bvh_grid.gs = {d.bvh_grid[3], d.bvh_grid[4], d.bvh_grid[5]};
+  k.bvh_grid.grs = {d.bvh_grid[6], d.bvh_grid[7], d.bvh_grid[8]};
   k.tile_live = d.tile_live;
   *ks = k;
   return GRT_OK;
@@ -445,11 +482,10 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->s_first = 0;
   j->pm.pos = j->pm.nrm = j->pm.w = nullptr;
   j->pm_batch = 0;
-  static const int shade_min = [] {
-    const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 0 = lockstep levels
-    return e ? std::max(0, std::min(64, atoi(e))) : 1;
-  }();
-  j->shade_min = shade_min;
+  const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 64 = every level in lockstep
+  j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 8;
+  e = getenv("GRT_BVH_INNER_WEIGHT");
+  j->inner_weight = e ? std::max(1, std::min(1024, atoi(e))) : 2;
   return GRT_OK;
 }
 
@@ -488,8 +524,20 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   // opts->flags bits 0-3: kernel variant for A/B timing (0 = default)
   const int variant = o ? (o->flags & 15) : 0;
   unsigned long long* rcnt = (unsigned long long*)d_ray_count;
-  if (s->use_bvh)
+  if (s->use_bvh && variant == 5)  // every level in lockstep through path_advance (the state machine of the small scenes)
     hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  else if (s->use_bvh) {
+    const char* e = getenv("GRT_BVH_OCC");
+    const int occ = e ? atoi(e) : 7;
+    if (occ == 8 && ks.bvh_depth + 1 <= 20)
+      hipLaunchKernelGGL((k_pathtrace_bvh<8, 20>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+    else if (occ >= 7 && ks.bvh_depth + 1 <= 22)
+      hipLaunchKernelGGL((k_pathtrace_bvh<7, 22>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+    else if (occ == 5)
+      hipLaunchKernelGGL((k_pathtrace_bvh<5, GRT_BVH_STACK>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+    else
+      hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  }
   else if (scene_is_small(s) && variant == 4)  // wave queue of (pixel, sample) pairs (92 VGPRs): 45.9 ms vs 44.1 ms
     hipLaunchKernelGGL((k_pathtrace<GRT_FAST_PRIMS, true, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (!scene_is_small(s) || variant == 1)

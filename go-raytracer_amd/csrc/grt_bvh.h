@@ -13,16 +13,20 @@
 //   else   the smallest h wins, the lowest index among equal h (later objects replace the
 //          best only when strictly closer).
 //
-// Layout (HBM): a binary tree, 64 B per node = the boxes of BOTH children, so one fetch
-// decides two subtrees:
-//   nodes[4n+0] = (lo0.xyz, ref0)  nodes[4n+1] = (hi0.xyz, 0)
-//   nodes[4n+2] = (lo1.xyz, ref1)  nodes[4n+3] = (hi1.xyz, 0)
+// Layout (HBM): a binary tree, 32 B per node = the boxes of BOTH children, so one fetch
+// decides two subtrees.  The boxes live on a 16-bit grid over the scene's bounds (world =
+// gmin + q * gs per axis), rounded outward by one cell, so a node is two 16-byte words:
+//   nodes[2n+c] = (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, ref)   c = child 0, 1
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = first object slot << 3 | count (<= 7;
 //   2 per leaf walks fastest at C5, deeper scenes take 4 or 7 to fit the traversal stack).
-// Objects are re-ordered into leaf order (bprims: the 2 x float4 records of KScene::prims;
-// bids: slot -> index into Scene.Objects).  Object boxes are padded by a few ulps before the
-// unions are taken, so a subtree is never culled by a rounding difference between the slab
-// arithmetic here and the sphere arithmetic of sphere_hit32.
+// The walk is bound by the vector memory path (texture addresser busy 76 % of the kernel at C5
+// with 64-byte FP32 nodes), which moves bytes per lane: halving the node halves that traffic.
+// A ray is taken into grid coordinates once (BvhRay): t = q * (gs / D) - (O - gmin) / D.
+// Objects are re-ordered into leaf order (bprims: the 2 x float4 records of KScene::prims with
+// the last word replaced by object index << 1 | is_box, so a leaf needs no second table).
+// Object boxes are padded by a few ulps before the unions are taken and one grid cell after,
+// so a subtree is never culled by a rounding difference between the slab arithmetic here and
+// the object arithmetic of sphere_hit32 / aabb_hit32.
 // Traversal: one ray per lane, nearer child first, the other child on a per-lane stack in LDS
 // (stack[depth][lane]: conflict-free).
 #pragma once
@@ -32,18 +36,30 @@
 #define GRT_BVH_STACK 24
 #define GRT_BVH_DONE 0x7fffffff
 
+struct BvhRay {
+  f3 invD, OinvD;  // gs / D, (O - gmin) / D
+};
+template <class RAY>
+GRT_DEV void bvh_ray_setup(BvhRay& g, const RAY& r, const BvhGrid& G) {
+  const f3 invD = mk3(rcp32(r.D.x), rcp32(r.D.y), rcp32(r.D.z));
+  g.invD = G.gs * invD;
+  g.OinvD = mk3(r.O.x - G.gmin.x, r.O.y - G.gmin.y, r.O.z - G.gmin.z) * invD;
+}
+
 template <bool CAREFUL>
-GRT_DEV bool bvh_box(float4 lo, float4 hi, const Ray32& r, float tbest, float& tn) {
+GRT_DEV bool bvh_box(uint4 q, const BvhRay& r, f3 Og, float tbest, float& tn) {
+  const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
+  const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
   float x0, x1, y0, y1, z0, z1;
   if (!CAREFUL) {
-    x0 = fmaf(lo.x, r.invD.x, -r.OinvD.x), x1 = fmaf(hi.x, r.invD.x, -r.OinvD.x);
-    y0 = fmaf(lo.y, r.invD.y, -r.OinvD.y), y1 = fmaf(hi.y, r.invD.y, -r.OinvD.y);
-    z0 = fmaf(lo.z, r.invD.z, -r.OinvD.z), z1 = fmaf(hi.z, r.invD.z, -r.OinvD.z);
-  } else {  // a zero direction component: (b - O) * (+-inf); 0 * inf = NaN is dropped by min/max = miss,
+    x0 = fmaf(lx, r.invD.x, -r.OinvD.x), x1 = fmaf(hx, r.invD.x, -r.OinvD.x);
+    y0 = fmaf(ly, r.invD.y, -r.OinvD.y), y1 = fmaf(hy, r.invD.y, -r.OinvD.y);
+    z0 = fmaf(lz, r.invD.z, -r.OinvD.z), z1 = fmaf(hz, r.invD.z, -r.OinvD.z);
+  } else {  // a zero direction component: (q - O) * (+-inf); 0 * inf = NaN is dropped by min/max = miss,
             // which is right because every object lies strictly inside its padded box
-    x0 = (lo.x - r.O.x) * r.invD.x, x1 = (hi.x - r.O.x) * r.invD.x;
-    y0 = (lo.y - r.O.y) * r.invD.y, y1 = (hi.y - r.O.y) * r.invD.y;
-    z0 = (lo.z - r.O.z) * r.invD.z, z1 = (hi.z - r.O.z) * r.invD.z;
+    x0 = (lx - Og.x) * r.invD.x, x1 = (hx - Og.x) * r.invD.x;
+    y0 = (ly - Og.y) * r.invD.y, y1 = (hy - Og.y) * r.invD.y;
+    z0 = (lz - Og.z) * r.invD.z, z1 = (hz - Og.z) * r.invD.z;
   }
   tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
   const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
@@ -58,16 +74,18 @@ struct BvhHit {
   int qbest;
 };
 
-template <bool CAREFUL>
-GRT_DEV void bvh_object(float4 pa, float4 pb, int id, const Ray32& r, float bias, BvhHit& H) {
+template <bool CAREFUL, class RAY>
+GRT_DEV void bvh_object(float4 pa, float4 pb, const RAY& r, float bias, BvhHit& H) {
   float h = -1.0f;
+  const int id = (int)((uint32_t)__float_as_int(pb.w) >> 1);
   if (__float_as_int(pb.w) & 1) {
-    h = aabb_hit32<CAREFUL>(pa, pb, r, bias, 3.402823466e38f);  // t0, or -1
+    h = aabb_hit32<CAREFUL>(pa, pb, full_ray(r), bias, 3.402823466e38f);  // t0, or -1
   } else {
+    const float inva = ray_inva(r);
     const f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
-    const float k = dot3(oc, r.D) * r.inva;
+    const float k = dot3(oc, r.D) * inva;
     const f3 l = fma3(r.D, -k, oc);
-    const float sq = sqrt32((pb.x - dot3(l, l)) * r.inva);  // NaN when there is no real root
+    const float sq = sqrt32((pb.x - dot3(l, l)) * inva);  // NaN when there is no real root
     const float t1 = -k - sq, t2 = -k + sq;
     h = t1 > bias ? t1 : (t2 > bias ? t2 : -1.0f);
   }
@@ -98,52 +116,81 @@ GRT_DEV int bvh_walk_result(const BvhWalk& w, float& t_out) {
   t_out = w.H.tbest;
   return w.H.best;
 }
-// One round for the lanes that call it (the walking lanes of the wave): inner nodes until every one
-// of them holds a leaf or has finished (lanes at a leaf wait), then the leaves.
-template <bool CAREFUL>
-GRT_DEV void bvh_walk_round(const float4* __restrict__ nodes, const float4* __restrict__ bprims, const int* __restrict__ bids,
-                            const Ray32& r, float bias, BvhWalk& w, int* stack, int stride) {
-  int ref = w.ref, sp = w.sp;
-  while (__any(ref >= 0 && ref != GRT_BVH_DONE)) {
-    if (ref >= 0 && ref != GRT_BVH_DONE) {
-      const float4 a0 = nodes[4 * (size_t)ref], a1 = nodes[4 * (size_t)ref + 1];
-      const float4 b0 = nodes[4 * (size_t)ref + 2], b1 = nodes[4 * (size_t)ref + 3];
-      float tn0, tn1;
-      const bool h0 = bvh_box<CAREFUL>(a0, a1, r, w.H.tbest, tn0);
-      const bool h1 = bvh_box<CAREFUL>(b0, b1, r, w.H.tbest, tn1);
-      const int r0 = __float_as_int(a0.w), r1 = __float_as_int(b0.w);
-      if (h0 & h1) {
-        const bool first0 = tn0 <= tn1;
-        stack[sp * stride] = first0 ? r1 : r0;
-        sp++;
-        ref = first0 ? r0 : r1;
-      } else if (h0 | h1) {
-        ref = h0 ? r0 : r1;
-      } else if (sp > 0) {
-        ref = stack[--sp * stride];
-      } else {
-        ref = GRT_BVH_DONE;
-      }
-    }
-  }
-  if (ref != GRT_BVH_DONE) {  // a leaf
-    const int first = (~ref) >> 3, cnt = (~ref) & 7;
-    for (int j = 0; j < cnt; ++j) {
-      const float4 pa = bprims[2 * (size_t)(first + j)], pb = bprims[2 * (size_t)(first + j) + 1];
-      bvh_object<CAREFUL>(pa, pb, bids[first + j], r, bias, w.H);
-    }
-    ref = sp > 0 ? stack[--sp * stride] : GRT_BVH_DONE;
-  }
-  w.ref = ref, w.sp = sp;
+// Stack entry d of this lane.  stride > 0: `stack` is the lane's own column, entry d at
+// stack[d * stride].  stride == 0: `stack` is the wave's [depth][64] block and the lane index is
+// taken afresh at every access (two v_mbcnt) — a lane offset held in a VGPR across the walk is the
+// first thing the register allocator spills at 7 waves per SIMD, and a scratch reload per stack
+// access costs far more than recomputing it.
+GRT_DEV int* bvh_slot(int* stack, int stride, int d) {
+  if (stride > 0) return stack + d * stride;
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return stack + d * 64 + lane;
 }
 
+// One inner node for the lanes that call it (w.ref is an inner node): both children's boxes, the
+// nearer hit child next, the other on the stack.
+template <bool CAREFUL, class RAY>
+GRT_DEV void bvh_inner_apply(uint4 c0, uint4 c1, const BvhGrid& G, const RAY& r, const BvhRay& g, BvhWalk& w, int* stack, int stride) {
+  f3 Og = mk3(0.0f, 0.0f, 0.0f);  // (O - gmin) / gs: only rays with a zero direction component read it
+  if (CAREFUL) Og = mk3(r.O.x - G.gmin.x, r.O.y - G.gmin.y, r.O.z - G.gmin.z) * G.grs;
+  float tn0, tn1;
+  const bool h0 = bvh_box<CAREFUL>(c0, g, Og, w.H.tbest, tn0);
+  const bool h1 = bvh_box<CAREFUL>(c1, g, Og, w.H.tbest, tn1);
+  const int r0 = (int)c0.w, r1 = (int)c1.w;
+  if (h0 & h1) {
+    const bool first0 = tn0 <= tn1;
+    *bvh_slot(stack, stride, w.sp) = first0 ? r1 : r0;
+    w.sp++;
+    w.ref = first0 ? r0 : r1;
+  } else if (h0 | h1) {
+    w.ref = h0 ? r0 : r1;
+  } else if (w.sp > 0) {
+    w.ref = *bvh_slot(stack, stride, --w.sp);
+  } else {
+    w.ref = GRT_BVH_DONE;
+  }
+}
+template <bool CAREFUL, class RAY>
+GRT_DEV void bvh_inner_step(const uint4* __restrict__ nodes, const BvhGrid& G, const RAY& r, const BvhRay& g, BvhWalk& w, int* stack,
+                            int stride) {
+  const uint4 c0 = nodes[2 * (size_t)w.ref], c1 = nodes[2 * (size_t)w.ref + 1];
+  bvh_inner_apply<CAREFUL>(c0, c1, G, r, g, w, stack, stride);
+}
+// One leaf for the lanes that call it (w.ref is a leaf): its objects, then the next reference.
+template <bool CAREFUL, class RAY>
+GRT_DEV void bvh_leaf_step(const float4* __restrict__ bprims, const RAY& r, float bias, BvhWalk& w, int* stack, int stride) {
+  const int first = (~w.ref) >> 3, cnt = (~w.ref) & 7;
+  for (int j = 0; j < cnt; ++j) {
+    const float4 pa = bprims[2 * (size_t)(first + j)], pb = bprims[2 * (size_t)(first + j) + 1];
+    bvh_object<CAREFUL>(pa, pb, r, bias, w.H);
+  }
+  w.ref = w.sp > 0 ? *bvh_slot(stack, stride, --w.sp) : GRT_BVH_DONE;
+}
+// The first object of the leaf in hand has been fetched and tested: the rest of the leaf, or the
+// next reference when that was its last object.
+GRT_DEV void bvh_leaf_advance(BvhWalk& w, int* stack, int stride) {
+  const int first = (~w.ref) >> 3, cnt = (~w.ref) & 7;
+  if (cnt > 1) w.ref = ~(((first + 1) << 3) | (cnt - 1));
+  else w.ref = w.sp > 0 ? *bvh_slot(stack, stride, --w.sp) : GRT_BVH_DONE;
+}
+GRT_DEV bool bvh_at_inner(const BvhWalk& w) { return w.ref >= 0 && w.ref != GRT_BVH_DONE; }
+GRT_DEV bool bvh_at_leaf(const BvhWalk& w) { return w.ref < 0; }
+
+// Every lane of the wave traces one ray to the end (while-while: inner nodes until every walking
+// lane holds a leaf or has finished, then the leaves).
 template <bool CAREFUL>
-GRT_DEV int intersect_bvh_t(const float4* __restrict__ nodes, const float4* __restrict__ bprims, const int* __restrict__ bids,
-                            const Ray32& r, float bias, float& t_out, int* stack, int stride) {
+GRT_DEV int intersect_bvh_t(const uint4* __restrict__ nodes, const float4* __restrict__ bprims, const BvhGrid& G, const Ray32& r,
+                            float bias, float& t_out, int* stack, int stride) {
   BvhWalk w;
+  BvhRay g;
   bvh_walk_begin(w);
-  while (__any(w.ref != GRT_BVH_DONE))
-    if (w.ref != GRT_BVH_DONE) bvh_walk_round<CAREFUL>(nodes, bprims, bids, r, bias, w, stack, stride);
+  bvh_ray_setup(g, r, G);
+  while (__any(w.ref != GRT_BVH_DONE)) {
+    while (__any(bvh_at_inner(w)))
+      if (bvh_at_inner(w)) bvh_inner_step<CAREFUL>(nodes, G, r, g, w, stack, stride);
+    if (bvh_at_leaf(w)) bvh_leaf_step<CAREFUL>(bprims, r, bias, w, stack, stride);
+  }
   return bvh_walk_result(w, t_out);
 }
 static_assert(GRT_BVH_LEAF <= 7, "a leaf reference holds its object count in 3 bits");

@@ -72,6 +72,9 @@ struct KCamera {
   float hx, hy, hz;  // horizontal
   float vx, vy, vz;  // vertical
 };
+struct BvhGrid {
+  f3 gmin, gs, grs;  // grt_bvh.h: origin, cell size and 1 / cell size of the hierarchy's 16-bit grid
+};
 struct KScene {
   KCamera cam;
   int W, H, max_depth, n_prims;
@@ -83,9 +86,10 @@ struct KScene {
   const float4* __restrict__ mats;
   const float4* __restrict__ lights;
   // scenes above GRT_MAX_LINEAR_PRIMS objects (or grt_scene_desc.accel = GRT_ACCEL_BVH): grt_bvh.h
-  const float4* __restrict__ bvh_nodes;
+  const uint4* __restrict__ bvh_nodes;
   const float4* __restrict__ bvh_prims;
-  const int* __restrict__ bvh_ids;
+  BvhGrid bvh_grid;
+  int bvh_depth;
   // tile_live[ty * tiles_x + tx] == 0: no camera ray through 8x8 tile (tx, ty) can reach the scene's
   // bounding box (frustum-plane test in float64 on the host, grt_api.hip); its pixels are black
   const uint8_t* __restrict__ tile_live;
@@ -107,6 +111,29 @@ GRT_DEV void ray_setup(Ray32& r, f3 O, f3 D) {
   r.a = dot3(D, D);
   r.inva = rcp32(r.a);
 }
+// Ray with |D| = 1: a = inva = 1 fold away inside sphere_hit32.
+GRT_DEV void ray_setup_unit(Ray32& r, f3 O, f3 D) {
+  r.O = O;
+  r.D = D;
+  r.invD = mk3(rcp32(D.x), rcp32(D.y), rcp32(D.z));
+  r.OinvD = O * r.invD;
+  r.a = 1.0f;
+  r.inva = 1.0f;
+}
+// A unit-length ray that keeps no reciprocals (the hierarchy walk of k_pathtrace_bvh: box OBJECTS
+// recompute them, which keeps 6 VGPRs free across the walk; the values are those of ray_setup_unit).
+struct UnitRay {
+  f3 O, D;
+};
+GRT_DEV const Ray32& full_ray(const Ray32& r) { return r; }
+GRT_DEV Ray32 full_ray(const UnitRay& u) {
+  Ray32 r;
+  ray_setup_unit(r, u.O, u.D);
+  return r;
+}
+GRT_DEV float ray_inva(const Ray32& r) { return r.inva; }
+GRT_DEV float ray_inva(const UnitRay&) { return 1.0f; }
+GRT_DEV bool ray_has_zero(const UnitRay& r) { return (r.D.x == 0.0f) | (r.D.y == 0.0f) | (r.D.z == 0.0f); }
 GRT_DEV bool ray_has_zero(const Ray32& r) { return (r.D.x == 0.0f) | (r.D.y == 0.0f) | (r.D.z == 0.0f); }
 
 // Camera.Ray (camera.go:34-39): D = lowerLeft + horizontal*u + vertical*v - origin, unnormalised.
@@ -306,16 +333,6 @@ struct WaveQueue {
   const uint32_t* pixkey;  // LDS: RNG pixel keys of the tile's 64 pixels
 };
 
-// Ray with |D| = 1: a = inva = 1 fold away inside sphere_hit32.
-GRT_DEV void ray_setup_unit(Ray32& r, f3 O, f3 D) {
-  r.O = O;
-  r.D = D;
-  r.invD = mk3(rcp32(D.x), rcp32(D.y), rcp32(D.z));
-  r.OinvD = O * r.invD;
-  r.a = 1.0f;
-  r.inva = 1.0f;
-}
-
 // Scene.intersect with the objects in LDS: the loop is fully unrolled, every lane reads the
 // same address (an LDS broadcast, no bank conflict), the compiler hoists the reads ahead of
 // the arithmetic, and the box/sphere choice is a scalar branch on one SGPR bit mask.  (Holding
@@ -478,8 +495,8 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   float t;
   int id;
   if (NP < 0)  // NP < 0: bounding-volume hierarchy (grt_bvh.h), per-lane stack in LDS
-    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack, 256)
-                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack, 256);
+    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256)
+                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256);
   else if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
   else if (NP > 0)

@@ -28,9 +28,10 @@ struct DeviceScene {
   float4* mats = nullptr;
   float4* lights = nullptr;
   double* prims64 = nullptr;
-  float4* bvh_nodes = nullptr;  // grt_bvh.h; NULL for linear-scan scenes
+  uint4* bvh_nodes = nullptr;  // grt_bvh.h; NULL for linear-scan scenes
   float4* bvh_prims = nullptr;
-  int* bvh_ids = nullptr;
+  int bvh_depth = 0;            // deepest leaf: the traversal stack holds at most this many entries + 1
+  float bvh_grid[9] = {0, 0, 0, 1, 1, 1, 1, 1, 1};  // origin, cell size, 1 / cell size
   uint8_t* tile_live = nullptr;  // per 8x8 tile of the frame: can a camera ray reach the scene bounds?
 };
 

@@ -21,7 +21,8 @@ struct RenderJob {
   int s_first;          // first sample index (sample-range sharding; 0 otherwise)
   PmOut pm;             // photon-mapped trace(): gather requests of this launch (pos == NULL: off)
   int pm_batch;         // samples per pixel the request arrays hold
-  int shade_min;        // hierarchy scenes: lanes that must wait for shading before the wave shades (0: every level in lockstep)
+  int shade_min;        // hierarchy scenes: lanes that must wait for shading before the wave shades (64: every level in lockstep)
+  int inner_weight;     // hierarchy scenes: an inner-node step runs when inner lanes * this >= leaf lanes * 4
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -118,42 +119,6 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     result = mk3(Q.acc[3 * lane], Q.acc[3 * lane + 1], Q.acc[3 * lane + 2]);
-  } else if (NP < 0 && J.shade_min > 0) {
-    // Hierarchy scenes: walks differ a lot in length (C5: 20 % of the lanes active when every lane
-    // waits for the wave's longest walk before shading).  So a lane whose walk has ended WAITS, and
-    // the wave shades only once J.shade_min lanes wait or nobody walks; the others keep their walk
-    // (reference in hand, stack, hit so far) across the shading and go on afterwards.  Shading is
-    // ~10 % of a level's instructions, so running it at low occupancy of the lanes costs little and
-    // the walk rounds run with most lanes active.  Which lanes meet in a round depends only on the
-    // wave's own paths: the frame is reproducible and independent of sharding.
-    Ray32 r;
-    BvhWalk wk;
-    ray_setup_unit(r, L.O, L.D);
-    bvh_walk_begin(wk);
-    if (!alive) wk.ref = GRT_BVH_DONE;
-    int* stack = bvh_stack + threadIdx.x;
-    while (__any(alive)) {
-      for (;;) {
-        const bool walking = wk.ref != GRT_BVH_DONE;
-        if (!__any(walking)) break;
-        if (__builtin_popcountll(__ballot(alive & !walking)) >= J.shade_min) break;
-        if (walking) {
-          if (__any(ray_has_zero(r))) bvh_walk_round<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, wk, stack, 256);
-          else bvh_walk_round<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, wk, stack, 256);
-        }
-      }
-      if (alive & (wk.ref == GRT_BVH_DONE)) {
-        float t;
-        const int id = bvh_walk_result(wk, t);
-        n_rays++;
-        path_shade<false>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, r, id, t);
-        if (alive) {
-          ray_setup_unit(r, L.O, L.D);
-          bvh_walk_begin(wk);
-        }
-      }
-    }
-    result = L.acc;
   } else {
     const int pm_base = (lrow * S.W + x) * J.pm_batch - J.s_first;  // request slot of sample s: pm_base + s
     while (__any(alive)) {
@@ -168,6 +133,96 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     o[0] = result.x;
     o[1] = result.y;
     o[2] = result.z;
+  }
+  if (ray_count) {
+    unsigned long long tot = wave_sum_u32((unsigned)n_rays);
+    if (lane == 0) atomicAdd(ray_count, tot);
+  }
+}
+
+// k_pathtrace for hierarchy scenes (grt_bvh.h).  Same work items (one wave = one 8x8 tile x one
+// chunk of samples, one lane = one pixel) and the same per-sample RNG streams, but the level is
+// not run in lockstep: walks differ a lot in length (C5: 20 % of the lanes were active when every
+// lane waited for the wave's longest walk before shading).  A lane whose walk has ended waits, and
+// the wave shades once J.shade_min lanes wait or nobody walks; the other lanes keep their walk
+// (reference in hand, stack, hit so far) across the shading and go on afterwards.  Which lanes
+// meet in a round depends only on the wave's own paths: the frame is reproducible and independent
+// of sharding.  The kernel is bound by memory latency (dependent node fetches), so registers are
+// spent sparingly — the walk keeps the ray only in grid form (BvhRay) plus O and D — to hold
+// 6 waves per SIMD.
+template <int WAVES, int STACK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_pathtrace_bvh(
+    KScene S, RenderJob J, float* __restrict__ out, unsigned long long* __restrict__ ray_count) {
+  __shared__ int bvh_stack[STACK * 256];  // [wave][depth][lane]
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
+  const int tile = item % J.n_tiles, chunk = item / J.n_tiles;
+  const int tx = tile % J.tiles_x, lband = tile / J.tiles_x;
+  const int x = tx * 8 + (lane & 7);
+  const int y = (J.shard + lband * J.n_shards) * 8 + (lane >> 3);
+  const int lrow = lband * 8 + (lane >> 3);
+  const bool valid = (x < S.W) & (y < S.H);
+  const int s0 = J.s_first + chunk * J.chunk_spp;
+  const int s_end = min(s0 + J.chunk_spp, J.s_first + J.spp);
+  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  const float fx = (float)x, fy = (float)y;
+  int n_rays = 0;
+  bool alive = valid & (s0 < s_end);
+  if (S.tile_live && !S.tile_live[(J.shard + lband * J.n_shards) * J.tiles_x + tx]) alive = false;  // wave-uniform
+  LaneState L;
+  lane_begin(S, fx, fy, pix_key, s0, L);
+  UnitRay r;
+  BvhRay g;
+  BvhWalk wk;
+  r.O = L.O, r.D = L.D;
+  bvh_ray_setup(g, r, S.bvh_grid);
+  bvh_walk_begin(wk);
+  if (!alive) wk.ref = GRT_BVH_DONE;
+  int* stack = bvh_stack + STACK * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's [depth][lane] block
+  unsigned long long zmask = __ballot(alive & ray_has_zero(r));  // lanes whose ray needs the careful box form
+  for (;;) {
+    // Three kinds of step — an inner node, a leaf, a trace() level's shading — and every lane is
+    // ready for exactly one of them (or has no samples left).  The wave runs the step most lanes
+    // are ready for; lanes ready for another keep their state and wait.
+    const bool at_inner = bvh_at_inner(wk), at_leaf = bvh_at_leaf(wk);
+    const bool to_shade = alive & !at_inner & !at_leaf;
+    const unsigned long long mI = __ballot(at_inner), mL = __ballot(at_leaf), mS = __ballot(to_shade);
+    const int nI = __builtin_popcountll(mI), nL = __builtin_popcountll(mL), nS = __builtin_popcountll(mS);
+    if ((nI | nL | nS) == 0) break;
+    if (nS >= J.shade_min || (nI | nL) == 0) {
+      if (to_shade) {
+        float t;
+        const int id = bvh_walk_result(wk, t);
+        n_rays++;  // scene.go:242
+        Ray32 fr;
+        ray_setup_unit(fr, r.O, r.D);
+        L.O = r.O, L.D = r.D;
+        path_shade<false>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t);
+        if (alive) {
+          r.O = L.O, r.D = L.D;
+          bvh_ray_setup(g, r, S.bvh_grid);
+          bvh_walk_begin(wk);
+        }
+      }
+      zmask = (zmask & ~mS) | __ballot(to_shade & alive & ray_has_zero(r));
+    } else if (nI * J.inner_weight >= nL * 4) {
+      if (at_inner) {
+        if (zmask & mI) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
+        else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
+      }
+    } else {
+      if (at_leaf) {
+        if (zmask & mL) bvh_leaf_step<true>(S.bvh_prims, r, S.bias, wk, stack, 0);
+        else bvh_leaf_step<false>(S.bvh_prims, r, S.bias, wk, stack, 0);
+      }
+    }
+  }
+  if (valid) {
+    float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
+    o[0] = L.acc.x;
+    o[1] = L.acc.y;
+    o[2] = L.acc.z;
   }
   if (ray_count) {
     unsigned long long tot = wave_sum_u32((unsigned)n_rays);
@@ -294,8 +349,8 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   int id;
   __shared__ int bvh_stack[GRT_BVH_STACK * 256];
   if (S.bvh_nodes) {  // large scenes: FP32 through the hierarchy; the FP64 re-test (a linear scan) is not run
-    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256)
-                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256);
+    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256)
+                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256);
     force_mode = 1;
   } else {
     id = intersect32(S, r, t);
@@ -355,8 +410,8 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
     float t;
     int id;
     if (NP < 0)
-      id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256)
-                                  : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_ids, r, S.bias, t, bvh_stack + threadIdx.x, 256);
+      id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256)
+                                  : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256);
     else if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
     else if (NP > 0) id = intersect_lds<NP, PREFETCH>(T.tp, S.box_mask, r, S.bias, t);
     else id = intersect32_t<false>(S, r, t);

@@ -242,11 +242,12 @@ class Scene:
     __del__ = close
 
     @staticmethod
-    def opts(seed=None, first_device=0, n_devices=1, chunk_spp=0):
+    def opts(seed=None, first_device=0, n_devices=1, chunk_spp=0, variant=0):
+        """variant: kernel variant for A/B timing and cross-checks (grt_opts.flags bits 0-3; 0 = default)."""
         o = Opts()
         # the reference seeds with time.Now().Unix() (scene.go:114)
         o.seed = int(time.time()) if seed is None else int(seed)
-        o.first_device, o.n_devices, o.chunk_spp, o.flags = first_device, n_devices, chunk_spp, 0
+        o.first_device, o.n_devices, o.chunk_spp, o.flags = first_device, n_devices, chunk_spp, int(variant) & 15
         return o
 
     # scene.go:79

@@ -43,6 +43,23 @@ def test_paths_equal_the_linear_scan(pkg):
     assert np.abs(a - b).max() <= 1e-3 * a.max() or (a == b).mean() > 0.999
 
 
+def test_deferred_shading_equals_lockstep_levels(pkg, monkeypatch):
+    """k_pathtrace_bvh lets lanes whose walk has ended shade while the others keep walking; the
+    frame must not depend on when a lane is shaded.  Against itself with every level in lockstep
+    (threshold 64) and against k_pathtrace<-1> (variant 5: the small scenes' state machine)."""
+    scene = pkg.scenes.spheres(20000, 256, 144)
+    a = scene.RenderAccum(24, seed=3)
+    monkeypatch.setenv("GRT_BVH_SHADE_MIN", "64")
+    b = scene.RenderAccum(24, seed=3)
+    monkeypatch.setenv("GRT_BVH_SHADE_MIN", "7")
+    c = scene.RenderAccum(24, seed=3)
+    monkeypatch.delenv("GRT_BVH_SHADE_MIN")
+    d = scene.RenderAccum(24, seed=3, variant=5)
+    assert a.max() > 0
+    assert (a == b).all() and (a == c).all()
+    assert (a == d).mean() > 0.9999, (a == d).mean()   # a wave with a zero-component ray takes the careful box form
+
+
 def test_tiny_and_degenerate_scenes(pkg, ob):
     m = pkg.tracer.LambertMaterial((0.5, 0.5, 0.5))
     for objs in ([pkg.tracer.NewSphere((278, 278, 300), 100, m)],
