@@ -205,7 +205,8 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   float lo[3], hi[3];
   // Leaves of 2 objects walk fastest (measured at C5); deeper scenes take larger leaves so that the
   // balanced tree fits the per-lane traversal stack.
-  while (B.leaf < 7 && (((long long)B.leaf << (GRT_BVH_STACK - 2)) < (long long)n)) B.leaf = B.leaf == 2 ? 4 : 7;
+  if (const char* e = getenv("GRT_BVH_LEAF_OBJS")) B.leaf = std::max(1, std::min(7, atoi(e)));  // A/B knob
+  while (B.leaf < 7 && (((long long)B.leaf << (GRT_BVH_STACK - 2)) < (long long)n)) B.leaf = B.leaf < 2 ? 2 : (B.leaf < 4 ? 4 : 7);
   if (n <= B.leaf) {  // a single leaf still needs a root node: the second child is empty
     bvh_range_box(B, 0, n, lo, hi);
     B.n_nodes = 1;
@@ -483,7 +484,7 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->pm.pos = j->pm.nrm = j->pm.w = nullptr;
   j->pm_batch = 0;
   const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 64 = every level in lockstep
-  j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 8;
+  j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 10;
   e = getenv("GRT_BVH_INNER_WEIGHT");
   j->inner_weight = e ? std::max(1, std::min(1024, atoi(e))) : 2;
   return GRT_OK;

@@ -32,7 +32,7 @@
 #pragma once
 // (included from the middle of grt_device.h, after the per-object hit functions)
 
-#define GRT_BVH_LEAF 2
+#define GRT_BVH_LEAF 1
 #define GRT_BVH_STACK 24
 #define GRT_BVH_DONE 0x7fffffff
 
