@@ -240,11 +240,40 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     d.bvh_grid[c] = gmin[c], d.bvh_grid[3 + c] = gs[c], d.bvh_grid[6 + c] = 1.0f / gs[c];
   }
   d.bvh_depth = B.max_depth;
-  const size_t n_nodes = (size_t)B.n_nodes.load();
-  std::vector<uint4> qn(2 * n_nodes);
+  // Memory order of the nodes: the inner children of a node are neighbours (one 64-byte pair, even
+  // slot first), followed by the pair of the first child's children, then the rest of the first
+  // child's subtree, then the second child's.  A 128-byte cache line so holds a pair of siblings and
+  // the children of one of them: the far child, pushed while the near one is walked, arrives with it.
+  const size_t built = (size_t)B.n_nodes.load();
+  std::vector<int> slot_of(built, -1), node_at;
+  node_at.reserve(built + built / 2 + 2);
+  {
+    auto child = [&](int node, int c) { return __builtin_bit_cast(int, B.nodes[4 * (size_t)node + 2 * c].w); };
+    std::vector<int> todo{0};
+    slot_of[0] = 0;
+    node_at.push_back(0), node_at.push_back(-1);  // the root and a pad: pairs start on even slots
+    while (!todo.empty()) {
+      const int nd = todo.back();
+      todo.pop_back();
+      const int c0 = child(nd, 0), c1 = child(nd, 1);
+      if (c0 < 0 && c1 < 0) continue;
+      for (int c : {c0, c1}) {
+        if (c >= 0) slot_of[c] = (int)node_at.size();
+        node_at.push_back(c >= 0 ? c : -1);  // a leaf child leaves a pad
+      }
+      if (c1 >= 0) todo.push_back(c1);
+      if (c0 >= 0) todo.push_back(c0);  // walked first
+    }
+  }
+  const size_t n_nodes = node_at.size();
+  std::vector<uint4> qn(2 * n_nodes, make_uint4(0, 0, 0, (uint32_t)~0));
   bool grid_ok = true;
   for (size_t k = 0; k < 2 * n_nodes; ++k) {
-    const float4 l = B.nodes[2 * k], h = B.nodes[2 * k + 1];
+    if (node_at[k / 2] < 0) continue;  // pad: two empty leaves, never referenced
+    const size_t src = 2 * (size_t)node_at[k / 2] + (k & 1);
+    float4 l = B.nodes[2 * src];
+    const float4 h = B.nodes[2 * src + 1];
+    if (__builtin_bit_cast(int, l.w) >= 0) l.w = __builtin_bit_cast(float, slot_of[__builtin_bit_cast(int, l.w)]);
     const float fl[3] = {l.x, l.y, l.z}, fh[3] = {h.x, h.y, h.z};
     uint32_t ql[3], qh[3];
     for (int c = 0; c < 3; ++c) {

@@ -28,7 +28,8 @@ for cfg in ("c2", "c3", "c4", "c5"):
         out = subprocess.run([sys.executable, os.path.join(dst, "summarize_pmc.py"), pm], capture_output=True, text=True, check=True).stdout
         open(os.path.join(dst, f"{name}_{cfg}_pmc.json"), "w").write(out)
         if cfg == "c3":
-            d = json.loads(out).get("k_pathtrace<8, true, false>", {})
+            full = json.loads(out)
+            d = next((v for k, v in full.items() if k.startswith("k_pathtrace<8, true, false")), {})
             if "hbm_write_bytes" in d:
                 # k_pathtrace stores 12 B per pixel per chunk with dword stores (WRITE_SIZE is exact for those)
                 # and reads only the 0.5 KB scene: FETCH_SIZE raw (no wide coalesced reads to correct for)

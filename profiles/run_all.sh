@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile set (run on the GPU box from the repo root):  bash profiles/run_all.sh <tag>
-# Kernel-trace summaries for the four measured configs, then PMC passes for C3 and C4.
+# Kernel-trace summaries for the four measured configs, then PMC passes for every config.
 # Results under gpurun_out/<tag>/; profiles/collect.py copies the summaries into profiles/.
 set -u
 TAG=${1:-r01b}
@@ -23,4 +23,5 @@ cd "$ROOT"
 bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > "$OUT/pmc_c3.log" 2>&1 || exit 1
 bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c4 tools/bench_photon.py --cpu-queries 0 --rounds 2 > "$OUT/pmc_c4.log" 2>&1 || exit 1
 bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c2 tools/bench_primary.py --rounds 2 > "$OUT/pmc_c2.log" 2>&1 || exit 1
+bash profiles/run_pmc.sh gpurun_out/$TAG/pmc_c5 tools/bench_spheres.py --spp 16 --steps 1 --cpu-spheres 0 > "$OUT/pmc_c5.log" 2>&1 || exit 1
 echo done

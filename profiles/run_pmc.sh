@@ -21,4 +21,6 @@ run sq3 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTI
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
 run write WRITE_SIZE GRBM_COUNT || exit 1
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
+run ta TA_TA_BUSY_sum TA_BUSY_avr || exit 1
+run tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum || exit 1
 cd "$ROOT" && python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.json" && cat "$OUT/summary.json"
