@@ -20,6 +20,7 @@ GRT_JITTER_RNG = 1
 GRT_BAND_ROWS = 8
 GRT_ACCEL_AUTO = 0
 GRT_ACCEL_BVH = 1
+GRT_ACCEL_LINEAR = 2
 
 
 class Camera(C.Structure):

@@ -57,8 +57,10 @@ static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_
   if (n_prims < 0 || n_mats < 0 || (n_prims && !prims) || (n_mats && !mats))
     return grt_fail(GRT_EINVAL, "grt_scene_create: bad prim/material arrays");
   if (n_prims > GRT_MAX_PRIMS) return grt_fail(GRT_ELIMIT, "grt_scene_create: %d objects; at most %d", n_prims, GRT_MAX_PRIMS);
-  if (d->accel != GRT_ACCEL_AUTO && d->accel != GRT_ACCEL_BVH)
+  if (d->accel != GRT_ACCEL_AUTO && d->accel != GRT_ACCEL_BVH && d->accel != GRT_ACCEL_LINEAR)
     return grt_fail(GRT_EINVAL, "grt_scene_create: unknown accel %d", d->accel);
+  if (d->accel == GRT_ACCEL_LINEAR && n_prims > GRT_MAX_LINEAR_PRIMS)
+    return grt_fail(GRT_ELIMIT, "grt_scene_create: the linear scan takes at most %d objects (got %d)", GRT_MAX_LINEAR_PRIMS, n_prims);
   for (int i = 0; i < n_prims; ++i) {
     if (prims[i].kind != GRT_KIND_SPHERE && prims[i].kind != GRT_KIND_AABB)
       return grt_fail(GRT_EINVAL, "grt_scene_create: object %d has unknown kind %d", i, prims[i].kind);
@@ -73,19 +75,23 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   if (!out) return grt_fail(GRT_EINVAL, "grt_scene_create: out is NULL");
   int rc = validate_scene(desc, prims, n_prims, mats, n_mats);
   if (rc) return rc;
-  const bool use_bvh = n_prims > GRT_MAX_LINEAR_PRIMS || (desc->accel == GRT_ACCEL_BVH && n_prims > 0);
-  if (use_bvh)
-    for (int i = 0; i < n_prims; ++i) {
-      const grt_material& m = mats[prims[i].material];
-      // The direct-light branch of trace() (scene.go:322-346) walks every object in index order
-      // with a shrinking tNear: it has no order-free form, so it stays with the linear scan.
-      if (!m.normal && !(m.emittance > 0) && !m.lambert && !(m.reflectivity > 0) && !m.transparent)
-        return grt_fail(GRT_ELIMIT, "grt_scene_create: object %d has a plain DiffuseMaterial (material.go:20); its shadow loop "
-                        "(scene.go:336-344) needs the linear scan, which takes at most %d objects", i, GRT_MAX_LINEAR_PRIMS);
-    }
+  // The direct-light branch of trace() (scene.go:322-346) walks every object in index order with a
+  // shrinking tNear: it has no order-free form, so a scene with a plain DiffuseMaterial object
+  // (material.go:20) stays with the linear scan.
+  int diffuse_obj = -1;
+  for (int i = 0; i < n_prims && diffuse_obj < 0; ++i) {
+    const grt_material& m = mats[prims[i].material];
+    if (!m.normal && !(m.emittance > 0) && !m.lambert && !(m.reflectivity > 0) && !m.transparent) diffuse_obj = i;
+  }
+  const bool bvh_forced = n_prims > GRT_MAX_LINEAR_PRIMS || (desc->accel == GRT_ACCEL_BVH && n_prims > 0);
+  const bool use_bvh = bvh_forced || (desc->accel == GRT_ACCEL_AUTO && n_prims > GRT_BVH_AUTO_PRIMS && diffuse_obj < 0);
+  if (use_bvh && diffuse_obj >= 0)
+    return grt_fail(GRT_ELIMIT, "grt_scene_create: object %d has a plain DiffuseMaterial (material.go:20); its shadow loop "
+                    "(scene.go:336-344) needs the linear scan, which takes at most %d objects", diffuse_obj, GRT_MAX_LINEAR_PRIMS);
   grt_scene* s = new grt_scene;
   s->d = *desc;
   s->use_bvh = use_bvh;
+  s->bvh_forced = bvh_forced;
   s->prims.assign(prims, prims + n_prims);
   s->mats.assign(mats, mats + n_mats);
   for (int i = 0; i < n_prims; ++i) {  // NewScene, scene.go:40-51
@@ -830,6 +836,7 @@ GRT_API int grt_primary_hits(grt_scene* s, const grt_opts* o, int32_t jitter_mod
   if (rc) return rc;
   rc = kernel_view64(s, &k64);
   if (rc) return rc;
+  if (!s->bvh_forced) ks.bvh_nodes = nullptr;  // parity: the linear scan and its FP64 re-test whenever the scene allows it
   const size_t n = (size_t)ks.W * ks.H;
   const int force = o ? (o->flags >> 8) & 3 : 0;
   int* d_id = nullptr;

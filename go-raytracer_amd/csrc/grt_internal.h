@@ -13,6 +13,7 @@
 // The linear-scan kernels (the reference's own algorithm, scene.go:173) read every object
 // for every ray; beyond this many objects a scene goes through the BVH path instead.
 #define GRT_MAX_LINEAR_PRIMS 4096
+#define GRT_BVH_AUTO_PRIMS 128  // GRT_ACCEL_AUTO takes the hierarchy above this (tools/bench_crossover.py: 10.7 vs 9.5 ms at 128)
 #define GRT_MAX_PRIMS (1 << 26)
 
 int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -43,6 +44,7 @@ struct grt_scene {
   std::vector<int> tobjects;  // scene.go:48-50
   double light_area = 0.0;
   bool use_bvh = false;
+  bool bvh_forced = false;  // hierarchy by request or by size: the parity kernel walks it too (else linear scan + FP64 re-test)
   std::mutex mu;
   std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
 };

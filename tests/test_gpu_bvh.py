@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 def both(pkg, w, h, objs):
     cam = pkg.scenes.cornell_camera(w / h)
-    lin = pkg.tracer.Scene(w, h, cam, objs)
+    lin = pkg.tracer.Scene(w, h, cam, objs, accel=pkg._capi.GRT_ACCEL_LINEAR)
     bvh = pkg.tracer.Scene(w, h, cam, objs, accel=pkg._capi.GRT_ACCEL_BVH)
     return lin, bvh
 
@@ -107,6 +107,30 @@ def test_c5_spheres_scene_at_test_size(pkg, ob):
     b = ref.RenderAccum(16, seed=1) / 16
     rel = np.abs(a.mean((0, 1)) - b.mean((0, 1))) / b.mean((0, 1))
     assert (rel < 0.03).all(), rel
+
+
+def test_auto_takes_the_hierarchy_above_128_objects(pkg, ob):
+    """GRT_ACCEL_AUTO: linear scan up to 128 objects, hierarchy above unless an object is plain diffuse.
+    The parity kernel keeps the linear scan + float64 re-test for such scenes (ids exact against the oracle);
+    the renderer's frame equals the forced-hierarchy frame bit for bit."""
+    C = pkg._capi
+    cam = pkg.scenes.cornell_camera(128 / 96)
+    objs = pkg.scenes.random_objects(100, 100, 21, diffuse=False)
+    auto = pkg.tracer.Scene(128, 96, cam, objs)
+    forced = pkg.tracer.Scene(128, 96, cam, objs, accel=C.GRT_ACCEL_BVH)
+    lin = pkg.tracer.Scene(128, 96, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+    a, f, l = auto.RenderAccum(8, seed=5), forced.RenderAccum(8, seed=5), lin.RenderAccum(8, seed=5)
+    assert (a == f).all()
+    assert (a == l).mean() > 0.999
+    ids, t, _, _ = auto.PrimaryHits(0, 1)
+    rid, rt, _ = ob.OracleScene(auto.flat).PrimaryHits(0, 1)
+    assert (ids == rid).all()
+    small = pkg.tracer.Scene(128, 96, cam, objs[:100])                      # <= 128 objects: linear
+    assert (small.RenderAccum(4, seed=5) == pkg.tracer.Scene(128, 96, cam, objs[:100], accel=C.GRT_ACCEL_LINEAR).RenderAccum(4, seed=5)).all()
+    withd = pkg.scenes.random_objects(100, 100, 21, diffuse=True)           # a plain diffuse object: linear, not refused
+    pkg.tracer.Scene(64, 48, cam, withd).RenderAccum(2, seed=1)
+    with pytest.raises(C.GrtError, match="linear scan takes at most"):
+        pkg.scenes.spheres(5000, 64, 36, accel=C.GRT_ACCEL_LINEAR)
 
 
 def test_diffuse_material_is_refused_with_the_hierarchy(pkg):
