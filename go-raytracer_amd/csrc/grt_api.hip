@@ -562,7 +562,10 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   unsigned long long* rcnt = (unsigned long long*)d_ray_count;
   if (s->use_bvh && variant == 5)  // every level in lockstep through path_advance (the state machine of the small scenes)
     hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
-  else if (s->use_bvh) {
+  else if (s->use_bvh && variant == 6) {  // profiling build: d_ray_count holds 3 words (rays, inner nodes visited, objects tested)
+    if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..2]: a NULL counter was passed");
+    hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  } else if (s->use_bvh) {
     const char* e = getenv("GRT_BVH_OCC");
     const int occ = e ? atoi(e) : 7;
     if (occ == 8 && ks.bvh_depth + 1 <= 20)

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
 // of sharding.  The kernel is bound by memory latency (dependent node fetches), so registers are
 // spent sparingly — the walk keeps the ray only in grid form (BvhRay) plus O and D — to hold
 // 6 waves per SIMD.
-template <int WAVES, int STACK>
+// COUNT (profiling build): ray_count[1] += inner nodes visited (two box tests, 32 B
+// each), ray_count[2] += objects tested (32 B each).
+template <int WAVES, int STACK, bool COUNT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_pathtrace_bvh(
     KScene S, RenderJob J, float* __restrict__ out, unsigned long long* __restrict__ ray_count) {
   __shared__ int bvh_stack[STACK * 256];  // [wave][depth][lane]
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   if (!alive) wk.ref = GRT_BVH_DONE;
   int* stack = bvh_stack + STACK * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's [depth][lane] block
   unsigned long long zmask = __ballot(alive & ray_has_zero(r));  // lanes whose ray needs the careful box form
+  int n_inner = 0, n_objs = 0;
   for (;;) {
     // Three kinds of step — an inner node, a leaf, a trace() level's shading — and every lane is
     // ready for exactly one of them (or has no samples left).  The wave runs the step most lanes
@@ -207,11 +210,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
       }
       zmask = (zmask & ~mS) | __ballot(to_shade & alive & ray_has_zero(r));
     } else if (nI * J.inner_weight >= nL * 4) {
+      if (COUNT) n_inner += at_inner;
       if (at_inner) {
         if (zmask & mI) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
         else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
       }
     } else {
+      if (COUNT && at_leaf) n_objs += (~wk.ref) & 7;
       if (at_leaf) {
         if (zmask & mL) bvh_leaf_step<true>(S.bvh_prims, r, S.bias, wk, stack, 0);
         else bvh_leaf_step<false>(S.bvh_prims, r, S.bias, wk, stack, 0);
@@ -227,6 +232,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   if (ray_count) {
     unsigned long long tot = wave_sum_u32((unsigned)n_rays);
     if (lane == 0) atomicAdd(ray_count, tot);
+    if (COUNT) {
+      const unsigned long long ti = wave_sum_u32((unsigned)n_inner), to = wave_sum_u32((unsigned)n_objs);
+      if (lane == 0) atomicAdd(ray_count + 1, ti), atomicAdd(ray_count + 2, to);
+    }
   }
 }
 

@@ -60,6 +60,26 @@ def test_deferred_shading_equals_lockstep_levels(pkg, monkeypatch):
     assert (a == d).mean() > 0.9999, (a == d).mean()   # a wave with a zero-component ray takes the careful box form
 
 
+def test_counting_build_counts_the_same_rays(pkg):
+    """opts.flags = 6: the profiling build of the hierarchy kernel adds inner-node and
+    object-test counters; frame and ray count equal the production kernel's."""
+    import importlib
+    import torch
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    scene = pkg.scenes.spheres(20000, 192, 108)
+    ren = shard.SampleShardRenderer(scene, 8, 0, 1, seed=2)
+    ren.render()
+    torch.cuda.synchronize()
+    frame, rays = ren.rgb_sum.clone(), int(ren.ray_count[0])
+    ren.ray_count.zero_()
+    ren.opts.flags = 6
+    ren.render()
+    torch.cuda.synchronize()
+    c = ren.ray_count.tolist()
+    assert c[0] == rays and (ren.rgb_sum == frame).all()
+    assert c[1] > c[0] and 0 < c[2] < 20000 * c[0]                           # > 1 inner node per ray; far fewer tests than a scan
+
+
 def test_tiny_and_degenerate_scenes(pkg, ob):
     m = pkg.tracer.LambertMaterial((0.5, 0.5, 0.5))
     for objs in ([pkg.tracer.NewSphere((278, 278, 300), 100, m)],

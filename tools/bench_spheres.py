@@ -57,7 +57,14 @@ for k in range(a.steps):
     times.append((time.perf_counter() - w0, e0.elapsed_time(e1)))
 wall = sorted(t[0] for t in times)[len(times) // 2]
 kms = sorted(t[1] for t in times)[len(times) // 2]
-rays = float(ren.ray_count.item()) / a.steps
+rays = float(ren.ray_count[0].item()) / a.steps
+# executed tests: one more frame through the counting build of the kernel
+ren.ray_count.zero_()
+ren.opts.flags = 6
+ren.render()
+torch.cuda.synchronize()
+c_rays, c_inner, c_objs = (float(v) for v in ren.ray_count[:3].tolist())
+ren.opts.flags = 0
 if world > 1:
     st = torch.tensor([wall, rays], dtype=torch.float64, device=dev)
     mx = st.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -70,6 +77,17 @@ if rank == 0:
            "frame_s": wall, "kernel_ms_rank0": kms, "Msamples_per_s": W * H * a.spp / wall / 1e6,
            "rays_per_s": rays / wall, "rays_per_sample": rays / (W * H * a.spp),
            "mean_radiance": frame.mean((0, 1)).div(a.spp).tolist()}
+    if c_rays > 0:
+        # per ray, from device counters: inner nodes visited (32 B, two box tests of 25 flop) and objects tested
+        # (32 B record, 27 flop for a sphere); rates use this run's rays/s
+        rps = rays / wall
+        out["executed_tests"] = {"inner_nodes_per_ray": c_inner / c_rays, "objects_per_ray": c_objs / c_rays,
+                                 "flop_per_ray": (50 * c_inner + 27 * c_objs) / c_rays,
+                                 "bytes_per_ray": 32 * (c_inner + c_objs) / c_rays,
+                                 "executed_TFLOPs": (50 * c_inner + 27 * c_objs) / c_rays * rps / 1e12,
+                                 "fetched_GBps": 32 * (c_inner + c_objs) / c_rays * rps / 1e9,
+                                 "note": "rank 0's sample range, counting build (opts.flags = 6); the reference would run "
+                                         f"{a.spheres + 2} object tests per ray (scene.go:173)"}
     if a.cpu_spheres > 0 and world == 1:
         from oracle import binding as ob
         cw, ch, cspp = 640, 360, 8
