@@ -32,23 +32,33 @@ def max_shard_rows(height, n_shards):
     return len(band_rows(height, 0, n_shards))  # shard 0 always owns the most rows
 
 
-def gather_frame(local, height, rank, world, dst=0, group=None):
+def frame_row_source(height, world, max_rows):
+    """src[y] = position of global row y in the stacked per-rank buffers ([world * max_rows] rows)."""
+    src = [0] * height
+    for r in range(world):
+        for k, y in enumerate(band_rows(height, r, world)):
+            src[y] = r * max_rows + k
+    return src
+
+
+def gather_frame(local, height, rank, world, dst=0, group=None, cache=None):
     """local: [max_shard_rows, W, C] tensor holding this rank's packed bands (tail rows unused).
-    Returns the assembled [H, W, C] frame on rank `dst`, None elsewhere."""
+    Returns the assembled [H, W, C] frame on rank `dst`, None elsewhere.  `cache` (a dict the caller
+    keeps) holds the receive buffer and the row permutation between calls, so a repeated gather
+    allocates nothing and assembles the frame with one index_select."""
+    cache = {} if cache is None else cache
+    if rank == dst and "src" not in cache:
+        cache["src"] = torch.as_tensor(frame_row_source(height, world, local.shape[0]), device=local.device)
+        cache["stack"] = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        cache["frame"] = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if world == 1:
-        parts = [local]
+        cache["stack"][0].copy_(local)
     else:
-        parts = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-        dist.gather(local, parts, dst=dst, group=group)
+        dist.gather(local, list(cache["stack"].unbind(0)) if rank == dst else None, dst=dst, group=group)
         if rank != dst:
             return None
-    frame = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        rows = band_rows(height, r, world)
-        if rows:
-            idx = torch.as_tensor(rows, device=local.device)
-            frame.index_copy_(0, idx, parts[r][: len(rows)])
-    return frame
+    torch.index_select(cache["stack"].view((-1,) + tuple(local.shape[1:])), 0, cache["src"], out=cache["frame"])
+    return cache["frame"]
 
 
 class ShardRenderer:
@@ -67,6 +77,7 @@ class ShardRenderer:
         self.workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         self.workspace_bytes = nbytes
         self.ray_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._gather_cache = {}
         # stage the scene on this device now so that render() never allocates
         self.render()
         torch.cuda.synchronize(self.device)
@@ -79,7 +90,8 @@ class ShardRenderer:
                                             self.workspace_bytes, self.ray_count.data_ptr(), stream))
 
     def gather(self, dst=0):
-        return gather_frame(self.rgb_sum, self.scene.H, self.rank, self.world, dst)
+        """The assembled frame on rank dst (a buffer this renderer owns: the next gather overwrites it)."""
+        return gather_frame(self.rgb_sum, self.scene.H, self.rank, self.world, dst, cache=self._gather_cache)
 
     def tonemap(self, frame_sum):
         """[H, W, 3] float32 sums -> [H, W, 4] uint8 B,G,R,x on the device (scene.go:98-99,67-74)."""

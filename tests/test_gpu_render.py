@@ -134,7 +134,7 @@ def test_sample_range_frames_add_up(pkg):
         ren.render()
         torch.cuda.synchronize()
         total += ren.rgb_sum
-        rays += int(ren.ray_count.item())
+        rays += int(ren.ray_count[0])
     assert torch.allclose(total, full, rtol=1e-5, atol=1e-6)
     assert rays == scene.last_ray_count()
 
