@@ -75,23 +75,18 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   if (!out) return grt_fail(GRT_EINVAL, "grt_scene_create: out is NULL");
   int rc = validate_scene(desc, prims, n_prims, mats, n_mats);
   if (rc) return rc;
-  // The direct-light branch of trace() (scene.go:322-346) walks every object in index order with a
-  // shrinking tNear: it has no order-free form, so a scene with a plain DiffuseMaterial object
-  // (material.go:20) stays with the linear scan.
-  int diffuse_obj = -1;
+  int diffuse_obj = -1;  // a plain DiffuseMaterial object (material.go:20): direct light with shadow rays, photon storage
   for (int i = 0; i < n_prims && diffuse_obj < 0; ++i) {
     const grt_material& m = mats[prims[i].material];
     if (!m.normal && !(m.emittance > 0) && !m.lambert && !(m.reflectivity > 0) && !m.transparent) diffuse_obj = i;
   }
   const bool bvh_forced = n_prims > GRT_MAX_LINEAR_PRIMS || (desc->accel == GRT_ACCEL_BVH && n_prims > 0);
-  const bool use_bvh = bvh_forced || (desc->accel == GRT_ACCEL_AUTO && n_prims > GRT_BVH_AUTO_PRIMS && diffuse_obj < 0);
-  if (use_bvh && diffuse_obj >= 0)
-    return grt_fail(GRT_ELIMIT, "grt_scene_create: object %d has a plain DiffuseMaterial (material.go:20); its shadow loop "
-                    "(scene.go:336-344) needs the linear scan, which takes at most %d objects", diffuse_obj, GRT_MAX_LINEAR_PRIMS);
+  const bool use_bvh = bvh_forced || (desc->accel == GRT_ACCEL_AUTO && n_prims > GRT_BVH_AUTO_PRIMS);
   grt_scene* s = new grt_scene;
   s->d = *desc;
   s->use_bvh = use_bvh;
   s->bvh_forced = bvh_forced;
+  s->has_diffuse = diffuse_obj >= 0;
   s->prims.assign(prims, prims + n_prims);
   s->mats.assign(mats, mats + n_mats);
   for (int i = 0; i < n_prims; ++i) {  // NewScene, scene.go:40-51
@@ -226,12 +221,12 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     if (B.max_depth + 1 > GRT_BVH_STACK)
       return grt_fail(GRT_ELIMIT, "grt_scene: hierarchy depth %d exceeds the traversal stack (%d)", B.max_depth, GRT_BVH_STACK);
   }
-  // leaf-order object records; the last word becomes index << 1 | is_box (grt_bvh.h)
+  // leaf-order object records; the last word becomes index << 3 | the three flag bits (grt_bvh.h)
   std::vector<float4> bp(2 * (size_t)n);
   for (int i = 0; i < n; ++i) {
     const int o = B.order[i];
     float4 pb = hp[2 * (size_t)o + 1];
-    pb.w = __builtin_bit_cast(float, (uint32_t)o << 1 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 1u));
+    pb.w = __builtin_bit_cast(float, (uint32_t)o << 3 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 7u));  // kind, emissive, transparent
     bp[2 * (size_t)i] = hp[2 * (size_t)o], bp[2 * (size_t)i + 1] = pb;
   }
   // The 16-bit grid: the scene's bounds widened by 1/1024 on each side, 65535 cells per axis.  Boxes
@@ -410,7 +405,7 @@ static int stage(grt_scene* s, DeviceScene& out) {
     for (int c = 0; c < 3; ++c) pos[c] = p.kind == GRT_KIND_AABB ? (p.b[c] + p.a[c]) * 0.5 : p.a[c];  // aabb.go:19, sphere.go:52
     const grt_material& m = s->mats[p.material];
     hl[2 * k] = make_float4((float)pos[0], (float)pos[1], (float)pos[2], (float)s->lights[k]);
-    hl[2 * k + 1] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], 0.0f);
+    hl[2 * k + 1] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], __builtin_bit_cast(float, (int)s->lights[k]));
   }
   DeviceScene d;
   GRT_HIP(hipMalloc(&d.prims, hp.size() * sizeof(float4)));
@@ -543,8 +538,7 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   if (rc) return rc;
   j.s_first = sample_first;
   j.pm.pos = pm_pos, j.pm.nrm = pm_nrm, j.pm.w = pm_w, j.pm_batch = pm_batch;
-  if (pm_pos && (s->use_bvh || pm_batch < samples))
-    return grt_fail(GRT_EINVAL, "photon-mapped render: batch %d < samples %d, or a hierarchy scene", pm_batch, samples);
+  if (pm_pos && pm_batch < samples) return grt_fail(GRT_EINVAL, "photon-mapped render: batch %d < samples %d", pm_batch, samples);
   if (j.rows_local == 0) return GRT_OK;
   const uint64_t need = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
   if (need > workspace_bytes || (need && !d_workspace))
@@ -564,11 +558,14 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
     hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (s->use_bvh && variant == 6) {  // profiling build: d_ray_count holds 3 words (rays, inner nodes visited, objects tested)
     if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..2]: a NULL counter was passed");
+    if (s->has_diffuse) return grt_fail(GRT_EINVAL, "render variant 6 (test counters) is built without the plain-diffuse branch");
     hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   } else if (s->use_bvh) {
     const char* e = getenv("GRT_BVH_OCC");
     const int occ = e ? atoi(e) : 7;
-    if (occ == 8 && ks.bvh_depth + 1 <= 20)
+    if (s->has_diffuse)
+      hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+    else if (occ == 8 && ks.bvh_depth + 1 <= 20)
       hipLaunchKernelGGL((k_pathtrace_bvh<8, 20>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
     else if (occ >= 7 && ks.bvh_depth + 1 <= 22)
       hipLaunchKernelGGL((k_pathtrace_bvh<7, 22>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);

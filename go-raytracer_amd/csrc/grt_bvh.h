@@ -23,7 +23,8 @@
 // with 64-byte FP32 nodes), which moves bytes per lane: halving the node halves that traffic.
 // A ray is taken into grid coordinates once (BvhRay): t = q * (gs / D) - (O - gmin) / D.
 // Objects are re-ordered into leaf order (bprims: the 2 x float4 records of KScene::prims with
-// the last word replaced by object index << 1 | is_box, so a leaf needs no second table).
+// the last word replaced by object index << 3 | transparent << 2 | emissive << 1 | is_box, so a
+// leaf needs no second table).
 // Object boxes are padded by a few ulps before the unions are taken and one grid cell after,
 // so a subtree is never culled by a rounding difference between the slab arithmetic here and
 // the object arithmetic of sphere_hit32 / aabb_hit32.
@@ -77,7 +78,7 @@ struct BvhHit {
 template <bool CAREFUL, class RAY>
 GRT_DEV void bvh_object(float4 pa, float4 pb, const RAY& r, float bias, BvhHit& H) {
   float h = -1.0f;
-  const int id = (int)((uint32_t)__float_as_int(pb.w) >> 1);
+  const int id = (int)((uint32_t)__float_as_int(pb.w) >> 3);
   if (__float_as_int(pb.w) & 1) {
     h = aabb_hit32<CAREFUL>(pa, pb, full_ray(r), bias, 3.402823466e38f);  // t0, or -1
   } else {
@@ -192,6 +193,57 @@ GRT_DEV int intersect_bvh_t(const uint4* __restrict__ nodes, const float4* __res
     if (bvh_at_leaf(w)) bvh_leaf_step<CAREFUL>(bprims, r, bias, w, stack, stride);
   }
   return bvh_walk_result(w, t_out);
+}
+// Any-hit query: is there an object with index in (idx_lo, idx_hi), every bit of `require` and no
+// bit of `reject` set in its flags (1 box, 2 emissive, 4 transparent), whose Hit against the window
+// (bias, cap) — the same aabb_hit32 / sphere_hit32 calls the linear loops make — is accepted
+// (ht > 0)?  This is the order-free core of the reference's two "does anything ... " loops:
+//   * the caustic filter of tracePhotons (scene.go:359-363): any transparent object, cap = +inf;
+//   * the shadow loop of trace() (scene.go:336-344), see direct_light_bvh in grt_device.h.
+// Wave-cooperative (while-while); a lane with active == false takes no part, a lane that has
+// found an object stops walking.
+template <bool CAREFUL>
+GRT_DEV bool bvh_any_hit(const uint4* __restrict__ nodes, const float4* __restrict__ bprims, const BvhGrid& G, const Ray32& r,
+                         float bias, float cap, int idx_lo, int idx_hi, int require, int reject, bool active, int* stack,
+                         int stride) {
+  BvhRay g;
+  bvh_ray_setup(g, r, G);
+  f3 Og = mk3(0.0f, 0.0f, 0.0f);
+  if (CAREFUL) Og = mk3(r.O.x - G.gmin.x, r.O.y - G.gmin.y, r.O.z - G.gmin.z) * G.grs;
+  int ref = active ? 0 : GRT_BVH_DONE, sp = 0;
+  bool found = false;
+  while (__any(ref != GRT_BVH_DONE)) {
+    while (__any(ref >= 0 && ref != GRT_BVH_DONE)) {
+      if (ref >= 0 && ref != GRT_BVH_DONE) {
+        const uint4 c0 = nodes[2 * (size_t)ref], c1 = nodes[2 * (size_t)ref + 1];
+        float tn0, tn1;
+        const bool h0 = bvh_box<CAREFUL>(c0, g, Og, cap, tn0);
+        const bool h1 = bvh_box<CAREFUL>(c1, g, Og, cap, tn1);
+        if (h0 & h1) {
+          *bvh_slot(stack, stride, sp) = (int)c1.w;
+          sp++;
+          ref = (int)c0.w;
+        } else if (h0 | h1) {
+          ref = h0 ? (int)c0.w : (int)c1.w;
+        } else {
+          ref = sp > 0 ? *bvh_slot(stack, stride, --sp) : GRT_BVH_DONE;
+        }
+      }
+    }
+    if (ref < 0) {
+      const int first = (~ref) >> 3, cnt = (~ref) & 7;
+      for (int j = 0; j < cnt; ++j) {
+        const float4 pa = bprims[2 * (size_t)(first + j)], pb = bprims[2 * (size_t)(first + j) + 1];
+        const int bits = __float_as_int(pb.w), id = (int)((uint32_t)bits >> 3);
+        if ((id > idx_lo) & (id < idx_hi) & ((bits & require) == require) & ((bits & reject) == 0)) {
+          const float ht = (bits & 1) ? aabb_hit32<CAREFUL>(pa, pb, r, bias, cap) : sphere_hit32(pa, pb, r, bias, cap);
+          found |= ht > 0.0f;
+        }
+      }
+      ref = (!found && sp > 0) ? *bvh_slot(stack, stride, --sp) : GRT_BVH_DONE;
+    }
+  }
+  return found;
 }
 static_assert(GRT_BVH_LEAF <= 7, "a leaf reference holds its object count in 3 bits");
 // Measured alternative (C5, 16 spp): the same tree folded into 4-ary nodes (128 B, four slab tests and

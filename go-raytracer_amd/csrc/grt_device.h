@@ -65,7 +65,8 @@ GRT_DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 // mats[2m]    = (r, g, b, refr_index)
 // mats[2m+1]  = (reflectivity, roughness, emittance, flags)   flags: 1 transparent,
 //               2 lambert, 4 normal
-// lights[2k]  = (Pos().xyz, prim index), lights[2k+1] = (Color.rgb, 0)   scene.go:42-46
+// lights[2k]  = (Pos().xyz, prim index as a float), lights[2k+1] = (Color.rgb, prim index as int bits)   scene.go:42-46;
+//               in ascending prim index (NewScene appends in object order)
 struct KCamera {
   float ox, oy, oz;  // origin
   float lx, ly, lz;  // lowerLeft - origin (folded on the host in float64)
@@ -457,6 +458,55 @@ GRT_DEV f3 direct_light32(const KScene& S, f3 p, f3 n, f3 color) {
   return result;
 }
 
+// The same for hierarchy scenes.  The shadow loop is order-dependent as written (tNear shrinks
+// with every accepted object, in index order), but its RESULT has an order-free form.  Call an
+// object a record when it is accepted at its turn.  The light is hidden iff some non-emissive
+// object is a record.  Up to the first such record every record is emissive, so the cap tNear
+// that a non-emissive object o meets is M(o) = the value left by the emissive records below o —
+// a chain computed from the (few) emissive objects alone, in index order.  Hence
+//     hidden  <=>  some non-emissive o has Hit_o(bias, M(o)) > 0
+// (if a non-emissive record exists, the first one meets exactly M(o); if none exists, every cap
+// is exactly M(o) and nothing is accepted).  M is constant between two emissive indices, so the
+// test is one any-hit query of the hierarchy per non-empty index range, with the same Hit calls
+// as the linear loop.  With the light first in Scene.Objects (the reference's scenes) that is one
+// query, capped at the distance to the light.
+GRT_DEV f3 direct_light_bvh(const KScene& S, f3 p, f3 n, f3 color, bool active, int* stack, int stride) {
+  f3 result = mk3(0.0f, 0.0f, 0.0f);
+  for (int li = 0; li < S.n_lights; ++li) {
+    float4 lp = S.lights[2 * li], lc = S.lights[2 * li + 1];
+    f3 dir = unit3(mk3(lp.x - p.x, lp.y - p.y, lp.z - p.z));
+    float fd = fmaxf(dot3(n, dir), 0.0f);
+    Ray32 sr;
+    ray_setup(sr, p, dir);
+    const bool careful = __any(active & ray_has_zero(sr));
+    float tn = 3.402823466e38f;
+    int prev = -1;
+    bool hidden = false;
+    for (int e = 0; e <= S.n_lights; ++e) {
+      const int ei = e < S.n_lights ? __float_as_int(S.lights[2 * e + 1].w) : S.n_prims;  // wave-uniform
+      if (ei > prev + 1) {  // non-emissive objects with index in (prev, ei) meet the cap tn
+        const bool go = active & !hidden;
+        const bool f = careful ? bvh_any_hit<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, sr, S.bias, tn, prev, ei, 0, 2, go, stack, stride)
+                               : bvh_any_hit<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, sr, S.bias, tn, prev, ei, 0, 2, go, stack, stride);
+        hidden |= f;
+      }
+      if (e < S.n_lights) {  // the emissive object itself: accepted, it shrinks the cap and hides nothing
+        const float4 pa = S.prims[2 * ei], pb = S.prims[2 * ei + 1];
+        float ht;
+        if (__float_as_int(pb.w) & 1)
+          ht = careful ? aabb_hit32<true>(pa, pb, sr, S.bias, tn) : aabb_hit32<false>(pa, pb, sr, S.bias, tn);
+        else
+          ht = sphere_hit32(pa, pb, sr, S.bias, tn);
+        if (ht > 0.0f) tn = ht;
+      }
+      prev = ei;
+    }
+    float k = fd * (hidden ? 0.0f : 1.0f);
+    result = result + mk3(color.x * k * lc.x, color.y * k * lc.y, color.z * k * lc.z);
+  }
+  return result;
+}
+
 // Birth of sample `s` of the lane's pixel: scene.go:93-95 with the jitter (u1,u2) supplied.
 GRT_DEV void primary_unit(const KScene& S, float fx, float fy, float u1, float u2, f3& O, f3& D) {
   float u = (fx + u1) * (1.0f / (float)S.W);
@@ -474,10 +524,13 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
   L.depth = 1;
 }
 
-template <bool QUEUE>
+// DIRECT: how the plain-diffuse branch finds its shadows: 0 linear loop (direct_light32), 1 the scene has
+// no plain-diffuse object (hierarchy scenes without one: the branch is compiled out), 2 hierarchy.
+template <bool QUEUE, int DIRECT = 0>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t,
-                        WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0);
+                        WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, int* bvh_stack = nullptr,
+                        int bvh_stride = 0);
 
 // One level of trace() for one lane.  NP > 0: tp (objects) and tm (materials) are LDS copies
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
@@ -504,15 +557,15 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   else
     id = intersect32_t<false>(S, r, t);
   n_rays++;                                         // scene.go:242
-  path_shade<QUEUE>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base);
+  path_shade<QUEUE, NP < 0 ? 2 : 0>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base, bvh_stack, 256);
 }
 
 // Everything of one trace() level after intersect(): Surface, material dispatch, the radiance a
 // terminating level carries, and the lane's next ray (same path, or the next sample's primary ray).
-template <bool QUEUE>
+template <bool QUEUE, int DIRECT>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
-                        const PmOut* pm, int pm_base) {
+                        const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride) {
   const bool hit = id >= 0;                         // scene.go:244
   const int idc = hit ? id : 0;
   const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];
@@ -532,9 +585,11 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   f3 rad = mk3(0.0f, 0.0f, 0.0f);
   if (is_emit) rad = color * m1.z;                                                              // scene.go:279
   if (is_normal) rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);      // scene.go:275
-  if (__builtin_expect(__any(is_diff), 0)) {
+  if (DIRECT != 1 && __builtin_expect(__any(is_diff), 0)) {
+    f3 direct = mk3(0.0f, 0.0f, 0.0f);
+    if (DIRECT == 2) direct = direct_light_bvh(S, p, n, color, is_diff, bvh_stack, bvh_stride);  // wave-cooperative
     if (is_diff) {
-      rad = direct_light32(S, p, n, color);                                                      // scene.go:322-346
+      rad = DIRECT == 2 ? direct : direct_light32(S, p, n, color);                               // scene.go:322-346
       if (pm && pm->pos) {                                                                       // scene.go:308-320
         const size_t slot = 3 * (size_t)(pm_base + L.s);
         const f3 w = (L.thr * color) * 0.318309886183790672f;  // BRDF = 1/pi (:309), Times(m.Color) (:319)

@@ -44,6 +44,7 @@ struct grt_scene {
   std::vector<int> tobjects;  // scene.go:48-50
   double light_area = 0.0;
   bool use_bvh = false;
+  bool has_diffuse = false;  // some object is plain diffuse (shadow rays, photon storage)
   bool bvh_forced = false;  // hierarchy by request or by size: the parity kernel walks it too (else linear scan + FP64 re-test)
   std::mutex mu;
   std::map<int, DeviceScene> dev;  // staged copies, one per HIP device

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
 // 6 waves per SIMD.
 // COUNT (profiling build): ray_count[1] += inner nodes visited (two box tests, 32 B
 // each), ray_count[2] += objects tested (32 B each).
-template <int WAVES, int STACK, bool COUNT = false>
+// DIFFUSE: the scene holds plain-diffuse objects: their shadow rays (and, with photon maps, their gather
+// requests) go through path_shade's hierarchy branch; without them that code is compiled out.
+template <int WAVES, int STACK, bool COUNT = false, bool DIFFUSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_pathtrace_bvh(
     KScene S, RenderJob J, float* __restrict__ out, unsigned long long* __restrict__ ray_count) {
   __shared__ int bvh_stack[STACK * 256];  // [wave][depth][lane]
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   bvh_walk_begin(wk);
   if (!alive) wk.ref = GRT_BVH_DONE;
   int* stack = bvh_stack + STACK * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's [depth][lane] block
+  const int pm_base = DIFFUSE ? (lrow * S.W + x) * J.pm_batch - J.s_first : 0;  // request slot of sample s: pm_base + s
   unsigned long long zmask = __ballot(alive & ray_has_zero(r));  // lanes whose ray needs the careful box form
   int n_inner = 0, n_objs = 0;
   for (;;) {
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         Ray32 fr;
         ray_setup_unit(fr, r.O, r.D);
         L.O = r.O, L.D = r.D;
-        path_shade<false>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t);
+        path_shade<false, DIFFUSE ? 2 : 1>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t, nullptr, &J.pm, pm_base, stack,
+                                           0);
         if (alive) {
           r.O = L.O, r.D = L.D;
           bvh_ray_setup(g, r, S.bvh_grid);

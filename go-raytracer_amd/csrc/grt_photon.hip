@@ -85,6 +85,8 @@ GRT_DEV int quantize_dir(f3 d) {
 __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos, float3 power0, int caustics,
                                                       unsigned long long first, int n_emit, int* __restrict__ flag,
                                                       float4* __restrict__ rec_pos, float4* __restrict__ rec_pow) {
+  __shared__ int bvh_stack[GRT_BVH_STACK * 256];  // hierarchy scenes: [depth][thread]
+  int* stack = bvh_stack + threadIdx.x;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n_emit;
   const unsigned long long e = first + (unsigned long long)(valid ? i : 0);
@@ -102,10 +104,23 @@ __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos
       Ray32 r;
       ray_setup(r, O, D);
       const bool careful = __any(ray_has_zero(r));
-      if (caustics && depth == 1 && !hits_transparent(S, r, careful)) alive = false;  // scene.go:359-363
+      if (caustics && depth == 1) {  // scene.go:359-363: the photon must start towards a transparent object
+        bool ht;
+        if (S.bvh_nodes)
+          ht = careful ? bvh_any_hit<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, 3.402823466e38f, -1, S.n_prims, 4, 0, true, stack, 256)
+                       : bvh_any_hit<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, 3.402823466e38f, -1, S.n_prims, 4, 0, true, stack, 256);
+        else
+          ht = hits_transparent(S, r, careful);
+        if (!ht) alive = false;
+      }
       if (alive) {
         float t;
-        int id = careful ? intersect32_t<true>(S, r, t) : intersect32_t<false>(S, r, t);  // scene.go:365
+        int id;  // scene.go:365
+        if (S.bvh_nodes)
+          id = careful ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, stack, 256)
+                       : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, stack, 256);
+        else
+          id = careful ? intersect32_t<true>(S, r, t) : intersect32_t<false>(S, r, t);
         if (id < 0) {
           alive = false;
         } else {
@@ -393,8 +408,6 @@ static int pick_device(const grt_opts* o, int* dev) {
 GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) {
   if (!s || !out || max_photons <= 0) return grt_fail(GRT_EINVAL, "grt_photon_build: bad argument");
   if (s->lights.empty()) return grt_fail(GRT_EINVAL, "grt_photon_build: the scene has no light (Emittance > 0)");
-  if (s->use_bvh)  // photons are stored on plain-diffuse surfaces only (scene.go:413-422), which a BVH scene cannot hold
-    return grt_fail(GRT_ELIMIT, "grt_photon_build: photon emission runs on linear-scan scenes (<= %d objects)", GRT_MAX_LINEAR_PRIMS);
   int dev;
   int rc = pick_device(o, &dev);
   if (rc) return rc;
@@ -569,7 +582,6 @@ GRT_API int grt_photon_emit_dev(grt_scene* s, const grt_opts* o, int32_t caustic
                                 void* stream) {
   if (!s || !d_pos4 || !d_pow4 || !d_stored || count <= 0) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: bad argument");
   if (light < 0 || light >= (int)s->lights.size()) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: light %d of %zu", light, s->lights.size());
-  if (s->use_bvh) return grt_fail(GRT_ELIMIT, "grt_photon_emit_dev: photon emission runs on linear-scan scenes");
   if (!d_workspace || workspace_bytes < grt_photon_emit_workspace_bytes(count))
     return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: workspace %llu bytes, need %llu", (unsigned long long)workspace_bytes,
                     (unsigned long long)grt_photon_emit_workspace_bytes(count));

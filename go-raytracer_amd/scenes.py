@@ -53,7 +53,7 @@ def cornell(width, height, variant="cornell8"):
 
 def random_objects(n_spheres, n_boxes, seed=7, diffuse=True):
     """Mixed spheres/boxes inside the Cornell room for intersection parity tests.
-    diffuse=False leaves out the plain DiffuseMaterial (not allowed in BVH scenes)."""
+    diffuse=False leaves out the plain DiffuseMaterial (no shadow rays: the lean hierarchy kernel)."""
     import random
 
     rnd = random.Random(seed)

@@ -88,12 +88,13 @@ typedef struct {
 } grt_scene_desc;
 
 /* How Scene.intersect finds the nearest object.  AUTO: the reference's linear scan up to 128
- * objects (and up to 4096 when an object has a plain DiffuseMaterial), a bounding-volume hierarchy
- * above (same result, see csrc/grt_bvh.h; measured crossover ~100 objects, 16x faster at 4096);
- * BVH forces the hierarchy, LINEAR the scan (<= 4096 objects).  Scenes that use the hierarchy
- * cannot hold plain DiffuseMaterial objects (their shadow loop, scene.go:336-344, is
- * order-dependent) and do not emit photons.  grt_primary_hits keeps the linear scan with its
- * float64 re-test whenever the scene has <= 4096 objects and BVH was not forced. */
+ * objects, a bounding-volume hierarchy above (same result, see csrc/grt_bvh.h; measured crossover
+ * ~100 objects, 16x faster at 4096); BVH forces the hierarchy, LINEAR the scan (<= 4096 objects).
+ * The shadow loop of the plain-diffuse branch (scene.go:336-344) and the caustic filter of
+ * tracePhotons (scene.go:359-363) run through the hierarchy in their order-free forms, so every
+ * material, photon emission and photon-mapped rendering work on hierarchy scenes.
+ * grt_primary_hits keeps the linear scan with its float64 re-test whenever the scene has <= 4096
+ * objects and BVH was not forced. */
 #define GRT_ACCEL_AUTO 0
 #define GRT_ACCEL_BVH 1
 #define GRT_ACCEL_LINEAR 2

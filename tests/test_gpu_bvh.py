@@ -130,7 +130,7 @@ def test_c5_spheres_scene_at_test_size(pkg, ob):
 
 
 def test_auto_takes_the_hierarchy_above_128_objects(pkg, ob):
-    """GRT_ACCEL_AUTO: linear scan up to 128 objects, hierarchy above unless an object is plain diffuse.
+    """GRT_ACCEL_AUTO: linear scan up to 128 objects, hierarchy above with or without plain-diffuse objects.
     The parity kernel keeps the linear scan + float64 re-test for such scenes (ids exact against the oracle);
     the renderer's frame equals the forced-hierarchy frame bit for bit."""
     C = pkg._capi
@@ -147,13 +147,57 @@ def test_auto_takes_the_hierarchy_above_128_objects(pkg, ob):
     assert (ids == rid).all()
     small = pkg.tracer.Scene(128, 96, cam, objs[:100])                      # <= 128 objects: linear
     assert (small.RenderAccum(4, seed=5) == pkg.tracer.Scene(128, 96, cam, objs[:100], accel=C.GRT_ACCEL_LINEAR).RenderAccum(4, seed=5)).all()
-    withd = pkg.scenes.random_objects(100, 100, 21, diffuse=True)           # a plain diffuse object: linear, not refused
+    withd = pkg.scenes.random_objects(100, 100, 21, diffuse=True)           # plain diffuse objects: hierarchy all the same
     pkg.tracer.Scene(64, 48, cam, withd).RenderAccum(2, seed=1)
     with pytest.raises(C.GrtError, match="linear scan takes at most"):
         pkg.scenes.spheres(5000, 64, 36, accel=C.GRT_ACCEL_LINEAR)
 
 
-def test_diffuse_material_is_refused_with_the_hierarchy(pkg):
-    objs = pkg.scenes.random_objects(5, 5, 1, diffuse=True)
-    with pytest.raises(pkg._capi.GrtError, match="DiffuseMaterial"):
-        pkg.tracer.Scene(32, 32, pkg.scenes.cornell_camera(1.0), objs, accel=pkg._capi.GRT_ACCEL_BVH)
+def test_plain_diffuse_objects_shadow_rays_through_the_hierarchy(pkg, ob):
+    """The shadow loop of trace() (scene.go:336-344) is order-dependent as written; direct_light_bvh
+    evaluates its order-free form with any-hit queries.  Every sample against the linear loop, the image
+    against the float64 oracle.  Lights first, in the middle and last in Scene.Objects (the cap of a
+    non-emissive object depends on the emissive objects BELOW it in index order), and two lights."""
+    C, T = pkg._capi, pkg.tracer
+    cam = pkg.scenes.cornell_camera(96 / 64)
+    base = pkg.scenes.random_objects(70, 70, 13, diffuse=True)            # light box = object 0
+    light, rest = base[0], base[1:]
+    second = T.NewSphere((300, 300, 250), 25, T.LightMaterial(T.NewColor(0.9, 0.8, 0.6), 6))
+    for objs in (base, rest[:60] + [light] + rest[60:], rest + [light], [light] + rest[:40] + [second] + rest[40:]):
+        lin = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+        bvh = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_BVH)
+        xy = np.stack(np.meshgrid(np.arange(0, 96, 2), np.arange(0, 64, 2)), -1).reshape(-1, 2)
+        lr, ln = lin.TraceSamples(xy, 8, seed=4)
+        br, bn = bvh.TraceSamples(xy, 8, seed=4)
+        same = (ln == bn) & (lr == br).all(-1)
+        assert same.mean() > 0.999, same.mean()
+        a, b = lin.RenderAccum(16, seed=2), bvh.RenderAccum(16, seed=2)     # k_pathtrace<0> vs k_pathtrace_bvh<.., DIFFUSE>
+        assert (a == b).mean() > 0.999 and a.max() > 0
+        assert (b == bvh.RenderAccum(16, seed=2, variant=5)).mean() > 0.999  # lockstep kernel, same branch
+    o = ob.OracleScene(bvh.flat).RenderAccum(16, seed=2) / 16
+    g = b.astype(np.float64) / 16
+    rel = np.abs(g.mean((0, 1)) - o.mean((0, 1))) / o.mean((0, 1))
+    assert (rel < 0.03).all(), rel                                        # FP32 vs float64 paths part ways at silhouettes (as at C5)
+
+
+def test_photon_pass_on_a_hierarchy_scene(pkg):
+    """tracePhotons (scene.go:354-424) through the hierarchy: the caustic filter (:359-363) is an any-hit
+    query over the transparent objects, intersect() the order-free walk.  Same photons as the linear scan."""
+    C, T = pkg._capi, pkg.tracer
+    objs = pkg.scenes.cornell_objects("cornell8d") + pkg.scenes.random_objects(60, 60, 17, diffuse=True)[6:]
+    cam = pkg.scenes.cornell_camera(1.0)
+    lin = T.Scene(64, 64, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+    bvh = T.Scene(64, 64, cam, objs, accel=C.GRT_ACCEL_BVH)
+    for caustics, n in ((False, 8000), (True, 1500)):
+        a = T.PhotonMap(n).build(lin, caustics=caustics, seed=5)
+        b = T.PhotonMap(n).build(bvh, caustics=caustics, seed=5)
+        assert a.count() == b.count() == n
+        assert abs(a.emitted() - b.emitted()) <= max(2, 1e-3 * a.emitted())
+        (ap, aw, at), (bp, bw, bt) = a.read(), b.read()
+        same = (ap == bp).all(1) & (aw == bw).all(1) & (at == bt).all(1)
+        assert same.mean() > 0.99, same.mean()
+    # and the photon-mapped trace() on the hierarchy scene (scene.go:308-320)
+    lin.globalPmap, lin.causticPmap = T.PhotonMap(8000).build(lin, seed=5), T.PhotonMap(1500).build(lin, caustics=True, seed=5)
+    bvh.globalPmap, bvh.causticPmap = lin.globalPmap, lin.causticPmap
+    fa, fb = lin.RenderAccumPhotonMapped(8, seed=1), bvh.RenderAccumPhotonMapped(8, seed=1)
+    assert np.isclose(fa, fb, rtol=1e-4, atol=1e-6).mean() > 0.999 and fa.max() > 0
