@@ -189,6 +189,7 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   BvhBuild B;
   B.hp = &hp;
   B.lo.resize(3 * (size_t)n), B.hi.resize(3 * (size_t)n), B.order.resize(n);
+  const float eye_r = (float)std::max({std::fabs(s->d.cam.origin[0]), std::fabs(s->d.cam.origin[1]), std::fabs(s->d.cam.origin[2])});
   for (int i = 0; i < n; ++i) {
     const float4 pa = hp[2 * (size_t)i], pb = hp[2 * (size_t)i + 1];
     const bool box = (__builtin_bit_cast(int, pb.w) & 1) != 0;
@@ -196,8 +197,9 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     for (int k = 0; k < 3; ++k) {
       float l = box ? std::min(c[k], e[k]) : c[k] - std::fabs(pa.w);
       float h = box ? std::max(c[k], e[k]) : c[k] + std::fabs(pa.w);
-      // padding: the slab arithmetic of a box around a sphere and sphere_hit32 round differently
-      const float pad = 4e-6f * (std::fabs(l) + std::fabs(h) + (h - l)) + 1e-30f;
+      // padding: the slab arithmetic of a box around a sphere and sphere_hit32 round differently, both
+      // with absolute errors that grow with the coordinates of the ray origin (the eye for primary rays)
+      const float pad = 4e-6f * (std::fabs(l) + std::fabs(h) + (h - l)) + 1e-6f * eye_r + 1e-30f;
       B.lo[3 * (size_t)i + k] = l - pad, B.hi[3 * (size_t)i + k] = h + pad;
     }
     B.order[i] = i;
@@ -236,8 +238,11 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   float gmin[3], gs[3];
   for (int c = 0; c < 3; ++c) {
     const double ext = std::max((double)hi[c] - (double)lo[c], 1e-30 + 1e-6 * (std::fabs((double)hi[c]) + std::fabs((double)lo[c])));
-    gmin[c] = (float)((double)lo[c] - ext / 1024.0);
-    gs[c] = (float)(ext * (1.0 + 2.0 / 1024.0) / 65535.0);
+    // a cell is never smaller than the rounding error of the slab arithmetic in world units (a small
+    // scene seen from far away): the one-cell padding below must cover that error
+    const double reach = std::max({std::fabs((double)lo[c]), std::fabs((double)hi[c]), (double)eye_r});
+    gs[c] = (float)std::max(ext * (1.0 + 2.0 / 1024.0) / 65535.0, 1e-6 * reach);
+    gmin[c] = (float)((double)lo[c] - std::max(ext / 1024.0, 4.0 * (double)gs[c]));
     d.bvh_grid[c] = gmin[c], d.bvh_grid[3 + c] = gs[c], d.bvh_grid[6 + c] = 1.0f / gs[c];
   }
   d.bvh_depth = B.max_depth;

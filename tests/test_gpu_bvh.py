@@ -93,6 +93,25 @@ def test_tiny_and_degenerate_scenes(pkg, ob):
         assert bi.max() <= 0 or len(objs) != 9                               # nine copies: id 0 everywhere
 
 
+def test_small_scene_seen_from_far_away(pkg):
+    """The rounding error of FP32 slab arithmetic grows with the distance of the eye, not with the size of
+    the scene: grid cells and box padding must cover it, or the hierarchy culls what the linear scan hits."""
+    T, C = pkg.tracer, pkg._capi
+    import random
+    rnd = random.Random(3)
+    m = T.LambertMaterial((0.5, 0.5, 0.5))
+    objs = [T.NewSphere((rnd.uniform(-5, 5), rnd.uniform(-5, 5), rnd.uniform(-5, 5)), rnd.uniform(0.3, 1.2), m) for _ in range(40)]
+    objs += [T.NewAABB((x, -6, -1), (x + 0.7, -5.5, 1), m) for x in range(-5, 5)]
+    for dist, fov in ((2.0e4, 0.05), (3.0e5, 0.0035)):
+        cam = T.NewCamera((3.0, 2.0, -dist), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), fov, 1.0)
+        lin = T.Scene(128, 128, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+        bvh = T.Scene(128, 128, cam, objs, accel=C.GRT_ACCEL_BVH)
+        li, lt, _, _ = lin.PrimaryHits(1, 2, mode=1)
+        bi, bt, _, _ = bvh.PrimaryHits(1, 2)
+        assert (li >= 0).mean() > 0.1
+        assert (li == bi).all() and (lt == bt).all()
+
+
 def test_origin_inside_and_entry_within_bias(pkg, ob):
     """aabb.go:44 returns the entry distance: a box the ray starts inside is no hit, a box
     entered within the bias wins over everything behind it.  Camera inside / just in front of boxes."""
