@@ -229,18 +229,21 @@ __global__ __launch_bounds__(256) void k_kd_iota(int* __restrict__ perm, int n) 
 }
 
 // segbox[3 seg + c] = min, segbox[3 S + 3 seg + c] = max of coordinate c (ordered images).
+// A wave owns KD_BBOX_RUN consecutive groups of 64 slots.  While the run lies inside one segment (the
+// top levels, where every wave of the grid would otherwise hit the same six words) the lanes keep
+// their min/max over the whole run and the wave issues ONE set of atomics; a run that crosses a
+// segment border is handled group by group.
+#define KD_BBOX_RUN 16
 __global__ __launch_bounds__(256) void k_kd_bbox(const float4* __restrict__ pos, const int* __restrict__ perm, int n, int depth,
                                                  int level, int n_seg, uint32_t* __restrict__ segbox) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = p < n;
-  const int seg = kd_leaf_of(valid ? p : n - 1, n, depth) >> (depth - level);
+  const int lane = threadIdx.x & 63;
+  const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * KD_BBOX_RUN);  // wave-uniform
+  if (first >= n) return;
+  const int last = (int)min((long long)n, first + 64 * KD_BBOX_RUN) - 1;
+  const int sh = depth - level;
+  const bool one_segment = (kd_leaf_of((int)first, n, depth) >> sh) == (kd_leaf_of(last, n, depth) >> sh);
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-  if (valid) {
-    const float4 q = pos[perm[p]];
-    lo[0] = hi[0] = ordered_bits(q.x), lo[1] = hi[1] = ordered_bits(q.y), lo[2] = hi[2] = ordered_bits(q.z);
-  }
-  const int seg0 = __builtin_amdgcn_readfirstlane(seg);
-  if (__all(seg == seg0)) {  // the usual case: the wave lies inside one segment
+  auto flush = [&](int seg) {  // wave reduction, then one atomic per word
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -249,17 +252,39 @@ __global__ __launch_bounds__(256) void k_kd_bbox(const float4* __restrict__ pos,
         hi[c] = max(hi[c], (uint32_t)__shfl_xor((int)hi[c], off, 64));
       }
     }
-    if ((threadIdx.x & 63) == 0)
+    if (lane == 0)
       for (int c = 0; c < 3; ++c) {
-        atomicMin(segbox + 3 * seg0 + c, lo[c]);
-        atomicMax(segbox + 3 * n_seg + 3 * seg0 + c, hi[c]);
+        atomicMin(segbox + 3 * seg + c, lo[c]);
+        atomicMax(segbox + 3 * n_seg + 3 * seg + c, hi[c]);
       }
-  } else if (valid) {
-    for (int c = 0; c < 3; ++c) {
-      atomicMin(segbox + 3 * seg + c, lo[c]);
-      atomicMax(segbox + 3 * n_seg + 3 * seg + c, hi[c]);
+  };
+  for (int g = 0; g < KD_BBOX_RUN; ++g) {
+    const long long p = first + 64 * g + lane;
+    if (first + 64 * g >= n) break;  // wave-uniform
+    const bool valid = p < n;
+    uint32_t v[3] = {0, 0, 0};
+    if (valid) {
+      const float4 q = pos[perm[p]];
+      v[0] = ordered_bits(q.x), v[1] = ordered_bits(q.y), v[2] = ordered_bits(q.z);
+    }
+    if (one_segment) {
+      if (valid)
+        for (int c = 0; c < 3; ++c) lo[c] = min(lo[c], v[c]), hi[c] = max(hi[c], v[c]);
+      continue;
+    }
+    const int seg = kd_leaf_of(valid ? (int)p : n - 1, n, depth) >> sh;
+    const int seg0 = __builtin_amdgcn_readfirstlane(seg);
+    if (__all(seg == seg0)) {
+      for (int c = 0; c < 3; ++c) lo[c] = valid ? v[c] : 0xffffffffu, hi[c] = valid ? v[c] : 0u;
+      flush(seg0);
+    } else if (valid) {
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(segbox + 3 * seg + c, v[c]);
+        atomicMax(segbox + 3 * n_seg + 3 * seg + c, v[c]);
+      }
     }
   }
+  if (one_segment) flush(kd_leaf_of((int)first, n, depth) >> sh);
 }
 
 __global__ __launch_bounds__(256) void k_kd_keys(const float4* __restrict__ pos, const int* __restrict__ perm, int n, int depth,
@@ -375,7 +400,8 @@ static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, gr
       const int n_seg = 1 << level;
       PTRY(hipMemsetAsync(d_segbox, 0xff, 3 * (size_t)n_seg * sizeof(uint32_t), nullptr));
       PTRY(hipMemsetAsync(d_segbox + 3 * (size_t)n_seg, 0, 3 * (size_t)n_seg * sizeof(uint32_t), nullptr));
-      hipLaunchKernelGGL(k_kd_bbox, dim3(grid), dim3(256), 0, nullptr, d_pos, perm_in, n, depth, level, n_seg, d_segbox);
+      hipLaunchKernelGGL(k_kd_bbox, dim3((unsigned)((n + 256 * KD_BBOX_RUN - 1) / (256 * KD_BBOX_RUN))), dim3(256), 0, nullptr, d_pos, perm_in,
+                         n, depth, level, n_seg, d_segbox);
       hipLaunchKernelGGL(k_kd_keys, dim3(grid), dim3(256), 0, nullptr, d_pos, perm_in, n, depth, level, n_seg, d_segbox, d_k0);
       PTRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, perm_in, perm_out, n, 0, 32 + level));
       std::swap(perm_in, perm_out);
