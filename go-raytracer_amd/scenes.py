@@ -72,9 +72,10 @@ def random_objects(n_spheres, n_boxes, seed=7, diffuse=True):
     return objs
 
 
-def spheres_flat(n_spheres, width, height, seed=1, accel=0):
+def spheres_flat(n_spheres, width, height, seed=1, accel=0, as_boxes=False):
     """(desc, prims, n_prims, mats, n_mats) of the C5 scene.  Objects 0 and 1 are the cornell8
-    light box and floor (main.go:41-42), objects 2.. the spheres."""
+    light box and floor (main.go:41-42), objects 2.. the spheres; as_boxes=True exports every sphere
+    as its bounding AABB instead (the "AABB-bounded" variant)."""
     import numpy as np
 
     g = np.random.Generator(np.random.Philox(seed))
@@ -87,12 +88,17 @@ def spheres_flat(n_spheres, width, height, seed=1, accel=0):
     a["kind"][0:2] = T.GRT_KIND_AABB
     a["a"][0], a["b"][0], a["material"][0] = (113, 548, 127), (443, 548.1, 432), 0
     a["a"][1], a["b"][1], a["material"][1] = (0, 0, 0), (555, 0.1, 555), 1
-    a["kind"][2:] = T.GRT_KIND_SPHERE
-    a["a"][2:] = c
-    a["radius"][2:] = r
+    if as_boxes:
+        a["kind"][2:] = T.GRT_KIND_AABB
+        a["a"][2:] = c - r[:, None]
+        a["b"][2:] = c + r[:, None]
+    else:
+        a["kind"][2:] = T.GRT_KIND_SPHERE
+        a["a"][2:] = c
+        a["radius"][2:] = r
     a["material"][2:] = 1 + (np.arange(n_spheres) % 4)
     return T.flatten_arrays(width, height, cornell_camera(width / height), a, mats, accel=accel)
 
 
-def spheres(n_spheres, width, height, seed=1, accel=0):
-    return T.Scene.from_flat(spheres_flat(n_spheres, width, height, seed, accel))
+def spheres(n_spheres, width, height, seed=1, accel=0, as_boxes=False):
+    return T.Scene.from_flat(spheres_flat(n_spheres, width, height, seed, accel, as_boxes))

@@ -26,6 +26,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--cpu-spheres", type=int, default=10000)
+ap.add_argument("--as-boxes", action="store_true", help="every sphere exported as its bounding AABB (SURVEY.md §8d)")
 a = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -36,7 +37,7 @@ if world > 1:
     dist.init_process_group("nccl", device_id=dev)
 W, H = a.width, a.height
 t0 = time.perf_counter()
-scene = pkg.scenes.spheres(a.spheres, W, H)
+scene = pkg.scenes.spheres(a.spheres, W, H, as_boxes=a.as_boxes)
 t_create = time.perf_counter() - t0
 t0 = time.perf_counter()
 ren = shard.SampleShardRenderer(scene, a.spp, rank, world, seed=1, device=dev)   # stages the scene: BVH build + upload
@@ -71,7 +72,7 @@ if world > 1:
     sm = st.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     wall, rays = mx[0].item(), sm[1].item()
 if rank == 0:
-    out = {"workload": f"C5: {a.spheres} spheres + light box + floor, {W}x{H}, {a.spp} spp, depth cap 6, seed 1, BVH",
+    out = {"workload": f"C5: {a.spheres} {'sphere-bounding boxes' if a.as_boxes else 'spheres'} + light box + floor, {W}x{H}, {a.spp} spp, depth cap 6, seed 1, BVH",
            "n_gpus": world, "sharding": "sample range per rank, RCCL reduce(sum) of the FP32 frame" if world > 1 else "none",
            "scene_create_s": t_create, "stage_s_incl_bvh_build_and_first_frame": t_stage,
            "frame_s": wall, "kernel_ms_rank0": kms, "Msamples_per_s": W * H * a.spp / wall / 1e6,
@@ -81,10 +82,11 @@ if rank == 0:
         # per ray, from device counters: inner nodes visited (32 B, two box tests of 25 flop) and objects tested
         # (32 B record, 27 flop for a sphere); rates use this run's rays/s
         rps = rays / wall
+        fo = 25 if a.as_boxes else 27
         out["executed_tests"] = {"inner_nodes_per_ray": c_inner / c_rays, "objects_per_ray": c_objs / c_rays,
-                                 "flop_per_ray": (50 * c_inner + 27 * c_objs) / c_rays,
+                                 "flop_per_ray": (50 * c_inner + fo * c_objs) / c_rays,
                                  "bytes_per_ray": 32 * (c_inner + c_objs) / c_rays,
-                                 "executed_TFLOPs": (50 * c_inner + 27 * c_objs) / c_rays * rps / 1e12,
+                                 "executed_TFLOPs": (50 * c_inner + fo * c_objs) / c_rays * rps / 1e12,
                                  "fetched_GBps": 32 * (c_inner + c_objs) / c_rays * rps / 1e9,
                                  "note": "rank 0's sample range, counting build (opts.flags = 6); the reference would run "
                                          f"{a.spheres + 2} object tests per ray (scene.go:173)"}
