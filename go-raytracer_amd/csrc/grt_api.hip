@@ -101,19 +101,25 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   return GRT_OK;
 }
 
+// hipFree(nullptr) is a no-op: a partly staged scene is released the same way.
+static void free_device_scene(DeviceScene& d) {
+  (void)hipFree(d.prims);
+  (void)hipFree(d.mats);
+  (void)hipFree(d.lights);
+  (void)hipFree(d.prims64);
+  (void)hipFree(d.bvh_nodes);
+  (void)hipFree(d.bvh_prims);
+  (void)hipFree(d.tile_live);
+  d = DeviceScene();
+}
+
 GRT_API void grt_scene_destroy(grt_scene* s) {
   if (!s) return;
   int cur = 0;
   bool have = hipGetDevice(&cur) == hipSuccess;
   for (auto& kv : s->dev) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    (void)hipFree(kv.second.prims);
-    (void)hipFree(kv.second.mats);
-    (void)hipFree(kv.second.lights);
-    (void)hipFree(kv.second.prims64);
-    (void)hipFree(kv.second.bvh_nodes);
-    (void)hipFree(kv.second.bvh_prims);
-    (void)hipFree(kv.second.tile_live);
+    free_device_scene(kv.second);
   }
   if (have) (void)hipSetDevice(cur);
   delete s;
@@ -413,21 +419,29 @@ static int stage(grt_scene* s, DeviceScene& out) {
     hl[2 * k + 1] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], __builtin_bit_cast(float, (int)s->lights[k]));
   }
   DeviceScene d;
-  GRT_HIP(hipMalloc(&d.prims, hp.size() * sizeof(float4)));
-  GRT_HIP(hipMalloc(&d.mats, hm.size() * sizeof(float4)));
-  GRT_HIP(hipMalloc(&d.lights, hl.size() * sizeof(float4)));
-  GRT_HIP(hipMalloc(&d.prims64, h64.size() * sizeof(double)));
-  GRT_HIP(hipMemcpy(d.prims, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(d.mats, hm.data(), hm.size() * sizeof(float4), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(d.lights, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
-  GRT_HIP(hipMemcpy(d.prims64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice));
-  if (s->use_bvh) {
-    int rc = stage_bvh(s, hp, d);
-    if (rc) return rc;
+  auto upload = [&]() -> int {
+    GRT_HIP(hipMalloc(&d.prims, hp.size() * sizeof(float4)));
+    GRT_HIP(hipMalloc(&d.mats, hm.size() * sizeof(float4)));
+    GRT_HIP(hipMalloc(&d.lights, hl.size() * sizeof(float4)));
+    GRT_HIP(hipMalloc(&d.prims64, h64.size() * sizeof(double)));
+    GRT_HIP(hipMemcpy(d.prims, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+    GRT_HIP(hipMemcpy(d.mats, hm.data(), hm.size() * sizeof(float4), hipMemcpyHostToDevice));
+    GRT_HIP(hipMemcpy(d.lights, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
+    GRT_HIP(hipMemcpy(d.prims64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (s->use_bvh) {
+      int rc = stage_bvh(s, hp, d);
+      if (rc) return rc;
+    }
+    const std::vector<uint8_t> live = cull_tiles(s);
+    GRT_HIP(hipMalloc(&d.tile_live, live.size()));
+    GRT_HIP(hipMemcpy(d.tile_live, live.data(), live.size(), hipMemcpyHostToDevice));
+    return GRT_OK;
+  };
+  const int rc = upload();
+  if (rc) {  // nothing of a scene that could not be staged stays on the device
+    free_device_scene(d);
+    return rc;
   }
-  const std::vector<uint8_t> live = cull_tiles(s);
-  GRT_HIP(hipMalloc(&d.tile_live, live.size()));
-  GRT_HIP(hipMemcpy(d.tile_live, live.data(), live.size(), hipMemcpyHostToDevice));
   s->dev[dev] = d;
   out = d;
   return GRT_OK;
