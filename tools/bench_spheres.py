@@ -26,6 +26,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--cpu-spheres", type=int, default=10000)
+ap.add_argument("--chunk-spp", type=int, default=0, help="samples per wave item (0 = the library's choice)")
 ap.add_argument("--as-boxes", action="store_true", help="every sphere exported as its bounding AABB (SURVEY.md §8d)")
 a = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -40,7 +41,7 @@ t0 = time.perf_counter()
 scene = pkg.scenes.spheres(a.spheres, W, H, as_boxes=a.as_boxes)
 t_create = time.perf_counter() - t0
 t0 = time.perf_counter()
-ren = shard.SampleShardRenderer(scene, a.spp, rank, world, seed=1, device=dev)   # stages the scene: BVH build + upload
+ren = shard.SampleShardRenderer(scene, a.spp, rank, world, seed=1, chunk_spp=a.chunk_spp, device=dev)   # stages the scene: BVH build + upload
 t_stage = time.perf_counter() - t0
 torch.cuda.synchronize()
 times = []
