@@ -535,7 +535,11 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 64 = every level in lockstep
   j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 10;
   e = getenv("GRT_BVH_INNER_WEIGHT");
-  j->inner_weight = e ? std::max(1, std::min(1024, atoi(e))) : 2;
+  j->inner_weight = e ? std::max(1, std::min(1024, atoi(e))) : 1;
+  e = getenv("GRT_BVH_INNER_AGAIN");
+  j->inner_again = e ? std::max(1, std::min(65, atoi(e))) : 1;
+  e = getenv("GRT_BVH_INNER_RUN");
+  j->inner_run = e ? std::max(1, std::min(64, atoi(e))) : 4;
   return GRT_OK;
 }
 

@@ -23,6 +23,8 @@ struct RenderJob {
   int pm_batch;         // samples per pixel the request arrays hold
   int shade_min;        // hierarchy scenes: lanes that must wait for shading before the wave shades (64: every level in lockstep)
   int inner_weight;     // hierarchy scenes: an inner-node step runs when inner lanes * this >= leaf lanes * 4
+  int inner_again;      // hierarchy scenes: another inner-node step follows at once while this many lanes still hold one ...
+  int inner_run;        // ... up to this many steps per scheduling round
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -218,6 +220,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
       if (at_inner) {
         if (zmask & mI) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
         else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
+      }
+      // more nodes right away while enough lanes still hold one (at most inner_run per round): saves
+      // scheduling rounds; the lanes at leaves or waiting for shading idle meanwhile
+      for (int it = 1; it < J.inner_run; ++it) {
+        const bool again = bvh_at_inner(wk);
+        const unsigned long long mA = __ballot(again);
+        if (__builtin_popcountll(mA) < J.inner_again) break;
+        if (COUNT) n_inner += again;
+        if (again) {
+          if (zmask & mA) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
+          else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
+        }
       }
     } else {
       if (COUNT && at_leaf) n_objs += (~wk.ref) & 7;
