@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
 // k_pathtrace for hierarchy scenes (grt_bvh.h).  Same work items (one wave = one 8x8 tile x one
 // chunk of samples, one lane = one pixel) and the same per-sample RNG streams, but the level is
 // not run in lockstep: walks differ a lot in length (C5: 20 % of the lanes were active when every
-// lane waited for the wave's longest walk before shading).  A lane whose walk has ended waits, and
-// the wave shades once J.shade_min lanes wait or nobody walks; the other lanes keep their walk
-// (reference in hand, stack, hit so far) across the shading and go on afterwards.  Which lanes
-// meet in a round depends only on the wave's own paths: the frame is reproducible and independent
-// of sharding.  The kernel is bound by memory latency (dependent node fetches), so registers are
-// spent sparingly — the walk keeps the ray only in grid form (BvhRay) plus O and D — to hold
-// 6 waves per SIMD.
+// lane waited for the wave's longest walk before shading).  Every lane is ready for one of three
+// steps (inner node, leaf, shading) and the wave runs, round by round, the step most lanes are
+// ready for; the others keep their state — reference in hand, stack, hit so far —
+// and wait.  Which lanes meet in a round depends only on the wave's own paths: the frame is
+// reproducible and independent of sharding and of the thresholds.  The kernel is bound by memory
+// latency (dependent node fetches), so registers are spent sparingly — the walk keeps the ray
+// only in grid form (BvhRay) plus O and D — to hold 7 waves per SIMD.
 // COUNT (profiling build): ray_count[1] += inner nodes visited (two box tests, 32 B
 // each), ray_count[2] += objects tested (32 B each).
 // DIFFUSE: the scene holds plain-diffuse objects: their shadow rays (and, with photon maps, their gather
