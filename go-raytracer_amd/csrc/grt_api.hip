@@ -468,6 +468,7 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
   k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_depth = d.bvh_depth;
+  k.n_mats = (int)s->mats.size();
   k.bvh_grid.gmin = {d.bvh_grid[0], d.bvh_grid[1], d.bvh_grid[2]};
   k.bvh_grid.gs = {d.bvh_grid[3], d.bvh_grid[4], d.bvh_grid[5]};
   k.bvh_grid.grs = {d.bvh_grid[6], d.bvh_grid[7], d.bvh_grid[8]};
@@ -599,6 +600,8 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   }
   else if (scene_is_small(s) && variant == 4)  // wave queue of (pixel, sample) pairs (92 VGPRs): 45.9 ms vs 44.1 ms
     hipLaunchKernelGGL((k_pathtrace<GRT_FAST_PRIMS, true, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  else if (!scene_is_small(s) && variant != 1 && (int)s->prims.size() <= GRT_LDS_PRIMS && (int)s->mats.size() <= GRT_LDS_PRIMS)
+    hipLaunchKernelGGL((k_pathtrace<0, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);  // objects in LDS, rolled loop
   else if (!scene_is_small(s) || variant == 1)
     hipLaunchKernelGGL((k_pathtrace<0, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (variant == 2)  // object reads hoisted out of the wave loop (115 VGPRs, 4 waves/SIMD): slower

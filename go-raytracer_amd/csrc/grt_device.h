@@ -91,6 +91,7 @@ struct KScene {
   const float4* __restrict__ bvh_prims;
   BvhGrid bvh_grid;
   int bvh_depth;
+  int n_mats;
   // tile_live[ty * tiles_x + tx] == 0: no camera ray through 8x8 tile (tx, ty) can reach the scene's
   // bounding box (frustum-plane test in float64 on the host, grt_api.hip); its pixels are black
   const uint8_t* __restrict__ tile_live;
@@ -196,6 +197,27 @@ GRT_DEV float sphere_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, flo
 
 // Scene.intersect (scene.go:169-181): nearest hit over all objects in order, tMax shrinking,
 // a candidate accepted when ht > 0.  Returns the object index or -1.
+// tp: the object records, in HBM (S.prims, read through the scalar cache) or an LDS copy of them
+template <bool CAREFUL>
+GRT_DEV int intersect_tab_t(const float4* __restrict__ tp, int n_prims, float bias, const Ray32& r, float& t_out) {
+  float tbest = 3.402823466e38f;
+  int best = -1;
+#pragma unroll 4
+  for (int i = 0; i < n_prims; ++i) {
+    float4 pa = tp[2 * i], pb = tp[2 * i + 1];
+    float ht;
+    if (__float_as_int(pb.w) & 1)
+      ht = aabb_hit32<CAREFUL>(pa, pb, r, bias, tbest);
+    else
+      ht = sphere_hit32(pa, pb, r, bias, tbest);
+    if (ht > 0.0f) {
+      best = i;
+      tbest = ht;
+    }
+  }
+  t_out = tbest;
+  return best;
+}
 template <bool CAREFUL>
 GRT_DEV int intersect32_t(const KScene& S, const Ray32& r, float& t_out) {
   float tbest = 3.402823466e38f;
@@ -542,7 +564,7 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
                           WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
-  if (RELOAD) asm volatile("" ::: "memory");
+  if (RELOAD && NP > 0) asm volatile("" ::: "memory");
   Ray32 r;
   ray_setup_unit(r, L.O, L.D);
   float t;
@@ -550,6 +572,8 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   if (NP < 0)  // NP < 0: bounding-volume hierarchy (grt_bvh.h), per-lane stack in LDS
     id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256)
                                 : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256);
+  else if (NP == 0 && RELOAD)  // mid-size scenes: the same loop over an LDS copy of the objects
+    id = __any(ray_has_zero(r)) ? intersect_tab_t<true>(tp, S.n_prims, S.bias, r, t) : intersect_tab_t<false>(tp, S.n_prims, S.bias, r, t);
   else if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
   else if (NP > 0)

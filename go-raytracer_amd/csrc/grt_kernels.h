@@ -38,6 +38,10 @@ GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
 // copied to LDS once per workgroup (NP > 0) and the objects are also loaded into registers
 // for the unrolled intersect loop.
 #define GRT_FAST_PRIMS 8
+// Mid-size scenes (9 .. GRT_LDS_PRIMS objects and materials, below the hierarchy's crossover): the
+// render kernel keeps the reference's linear loop but reads the records from an LDS copy (every lane
+// the same address: a broadcast) instead of waiting for a scalar load per object.
+#define GRT_LDS_PRIMS 192
 
 template <int NP>
 struct SceneTables {
@@ -46,9 +50,15 @@ struct SceneTables {
 };
 
 // The host pads the staged arrays to GRT_FAST_PRIMS records, so the copies are unconditional.
-template <int NP>
+template <int NP, bool LDSGEN = false>
 GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
-  if (NP > 0) {
+  if (NP == 0 && LDSGEN) {
+    for (int i = threadIdx.x; i < 2 * S.n_prims; i += blockDim.x) lds[i] = S.prims[i];
+    for (int i = threadIdx.x; i < 2 * S.n_mats; i += blockDim.x) lds[2 * GRT_LDS_PRIMS + i] = S.mats[i];
+    __syncthreads();
+    T.tp = lds;
+    T.tm = lds + 2 * GRT_LDS_PRIMS;
+  } else if (NP > 0) {
     // [0, 2NP) objects, [2NP, 4NP) materials (a scene never has more materials than objects
     // after de-duplication; the host checks n_mats <= NP before choosing this kernel)
     for (int i = threadIdx.x; i < 2 * NP; i += blockDim.x) {
@@ -72,12 +82,12 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
-  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  __shared__ float4 lds[NP > 0 ? 4 * NP : (NP == 0 && RELOAD ? 4 * GRT_LDS_PRIMS : 1)];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
   __shared__ float qacc[QUEUE ? 4 * 192 : 1];                  // wave-queue mode: [wave][pixel][rgb]
   __shared__ uint32_t qkey[QUEUE ? 4 * 64 : 1];
   SceneTables<NP> T;
-  load_tables<NP>(S, lds, T);
+  load_tables<NP, NP == 0 && RELOAD>(S, lds, T);
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
