@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 FLOP_PER_RAY_INTERSECT = 204  # 6 x AABB.Hit (25) + 2 x Sphere.Hit (27), SURVEY.md §8d
 FLOP_PER_RAY_SHADED = 324     # + ~120 shading flop per ray (Unit, At, Surface, BSDF sample)
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 (MI355X_MICROARCH.md, chip-level parameters)
+MEASURED_VALU_ISSUE_PER_S = 1.00e12  # v_fma_f32 wave-instructions per second, tools/microbench/valu_rate.hip on MI355X
 
 
 def cpu_baseline(pkg, width, height):
@@ -129,9 +130,19 @@ def main():
         # roofline of the dominant kernel (k_pathtrace), per launch on one GPU
         achieved = rays_per_launch_rank * FLOP_PER_RAY_SHADED / (kernel_ms * 1e-3) / 1e12
         traffic = None
+        issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and (W, H, S, world) == (1920, 1080, 1000, 1):
-            traffic = json.load(open(tpath)).get("k_pathtrace_hbm_bytes_per_launch")
+            prof = json.load(open(tpath))
+            traffic = prof.get("k_pathtrace_hbm_bytes_per_launch")
+            n_valu = prof.get("k_pathtrace_valu_wave_instructions_per_launch")
+            if n_valu:
+                # VALU wave-instructions of one launch (PMC, profiles/) over this run's launch time, against the
+                # issue rate tools/microbench/valu_rate.hip measures on this chip (1.00e12 v_fma_f32 per second)
+                issue = {"valu_wave_instructions_per_launch": n_valu, "achieved_per_s": n_valu / (kernel_ms * 1e-3),
+                         "measured_peak_per_s": MEASURED_VALU_ISSUE_PER_S,
+                         "frac": n_valu / (kernel_ms * 1e-3) / MEASURED_VALU_ISSUE_PER_S,
+                         "lane_utilisation": prof.get("k_pathtrace_lane_utilisation")}
         out = {
             "metric": "Msamples/s (paths/s) at 1920x1080",
             "value": samples_total / elapsed / 1e6,
@@ -165,6 +176,7 @@ def main():
                 "flop_per_ray": FLOP_PER_RAY_SHADED,
                 "achieved_intersection_only": rays_per_launch_rank * FLOP_PER_RAY_INTERSECT / (kernel_ms * 1e-3) / 1e12,
                 "kernel_ms_per_launch": kernel_ms,
+                "valu_issue": issue,
                 "rays_per_launch": rays_per_launch_rank,
                 "note": "algorithmic flop per intersect() call x calls per launch / HIP-event time of the launch; "
                         "div and sqrt count 1 flop (SURVEY.md §8d); MFMA is not used: nothing here is a contraction",

@@ -35,6 +35,9 @@ for cfg in ("c2", "c3", "c4", "c5"):
                 # and reads only the 0.5 KB scene: FETCH_SIZE raw (no wide coalesced reads to correct for)
                 json.dump({"k_pathtrace_hbm_bytes_per_launch": d["hbm_write_bytes"] + d.get("hbm_read_bytes_raw", 0.0),
                            "read_bytes": d.get("hbm_read_bytes_raw"), "write_bytes": d["hbm_write_bytes"],
+                           "k_pathtrace_valu_wave_instructions_per_launch": d.get("SQ_INSTS_VALU"),
+                           "k_pathtrace_lane_utilisation": (d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
+                                                            if d.get("SQ_ACTIVE_INST_VALU") else None),
                            "source": f"profiles/{name}_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB units)",
                            "config": "1920x1080, 1000 spp, 1 GPU"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("collected", sorted(os.listdir(dst)))
