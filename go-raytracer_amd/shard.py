@@ -5,7 +5,8 @@ The reference's unit of work is an image row handed to a goroutine and re-ordere
 collector (scene.go:107-132).  Here rows are dealt in interleaved bands of GRT_BAND_ROWS rows:
 band b belongs to rank b mod G.  Pixels are independent (scene.go:89-97 holds no cross-pixel
 state) and the counter RNG is keyed by the absolute pixel index, so the assembled frame is
-bit-identical for every G.  The only exchange is one gather of the finished bands to rank 0
+bit-identical for every G at a given chunk size (the automatic chunk size follows the shard's tile
+count: frames of different G then agree to FP32 rounding).  The only exchange is one gather of the finished bands to rank 0
 (W*H*3 float32 / G per rank); there is no collective inside the render.
 
 torch is plumbing here (device memory, streams, process groups); the pixels come from

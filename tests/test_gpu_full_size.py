@@ -1,0 +1,142 @@
+"""BASELINE.json's configurations at their FULL sizes, checked through properties that do not need the
+oracle to finish (it cannot at these sizes): determinism, independence of how the work is cut (bands,
+sample ranges, chunks, scheduling thresholds, query order), monotonicity, and totals that must agree.
+Each case runs in seconds on the GPU."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shard():
+    return importlib.import_module("go-raytracer_amd.shard")
+
+
+def test_c3_full_frame_is_independent_of_the_sharding(pkg, shard):
+    """C3: cornell8, 1920x1080, 1000 spp.  The frame assembled from 3 and from 8 shards of interleaved
+    8-row bands equals the single-shard frame bit for bit (RNG keyed by absolute pixel and sample, ordered
+    chunk sums) when the chunk size is the same — the automatic choice follows the shard's tile count, which
+    moves the chunk boundaries and with them the last bit of the FP32 sums: then the frames agree to rounding.
+    Twice in a row the same frame, and the ray counts add up."""
+    import torch
+
+    W, H, S = 1920, 1080, 1000
+    scene = pkg.scenes.cornell(W, H)
+    one = shard.ShardRenderer(scene, S, 0, 1, seed=1, chunk_spp=125)
+    one.render()
+    torch.cuda.synchronize()
+    whole, rays = one.gather(0).clone(), int(one.ray_count.item())
+    one.ray_count.zero_()
+    one.render()
+    torch.cuda.synchronize()
+    assert (one.gather(0) == whole).all()                                   # reproducible
+    assert 1.5 < rays / (W * H * S) < 2.5 and torch.isfinite(whole).all() and (whole >= 0).all()
+    for G in (3, 8):
+        frame = torch.empty_like(whole)
+        total = 0
+        for r in range(G):
+            ren = shard.ShardRenderer(scene, S, r, G, seed=1, chunk_spp=125)
+            ren.render()
+            torch.cuda.synchronize()
+            rows = torch.as_tensor(shard.band_rows(H, r, G), device=frame.device)
+            frame.index_copy_(0, rows, ren.rgb_sum[: len(rows)])
+            total += int(ren.ray_count.item())
+        assert (frame == whole).all(), G
+        assert total == rays
+    auto = shard.ShardRenderer(scene, S, 1, 8, seed=1)                       # automatic chunk size: 16 spp at 8 shards
+    auto.render()
+    torch.cuda.synchronize()
+    rows = torch.as_tensor(shard.band_rows(H, 1, 8), device=whole.device)
+    assert torch.allclose(auto.rgb_sum[: len(rows)], whole[rows], rtol=2e-5, atol=1e-4)
+    # the tone-mapped bytes of the full frame: B,G,R in [0,255], the 4th byte untouched
+    px = one.tonemap(whole)
+    assert px.shape == (H, W, 4) and int(px[..., 3].max()) == 0 and int(px[..., :3].max()) == 255
+
+
+def test_c5_full_scene_is_independent_of_scheduling_and_sample_split(pkg, shard, monkeypatch):
+    """C5: 10^6 spheres, 1920x1080 (8 spp here).  The frame does not depend on the scheduling thresholds of
+    k_pathtrace_bvh (bit-identical), the counting build traces the same rays, and the frames of two sample
+    ranges add up to the whole (FP32 addition order aside)."""
+    import torch
+
+    W, H, S = 1920, 1080, 8
+    scene = pkg.scenes.spheres(1000000, W, H)
+    ren = shard.SampleShardRenderer(scene, S, 0, 1, seed=1)
+    ren.render()
+    torch.cuda.synchronize()
+    whole, rays = ren.rgb_sum.clone(), int(ren.ray_count[0])
+    assert whole.max() > 0 and torch.isfinite(whole).all()
+    for env in ({"GRT_BVH_SHADE_MIN": "64"}, {"GRT_BVH_INNER_RUN": "1", "GRT_BVH_INNER_WEIGHT": "4"}, {"GRT_BVH_OCC": "6"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ren.ray_count.zero_()
+        ren.render()
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (ren.rgb_sum == whole).all(), env
+        assert int(ren.ray_count[0]) == rays
+    ren.ray_count.zero_()
+    ren.opts.flags = 6                                                       # counting build
+    ren.render()
+    torch.cuda.synchronize()
+    ren.opts.flags = 0
+    c = ren.ray_count.tolist()
+    assert c[0] == rays and (ren.rgb_sum == whole).all()
+    assert 20 * rays < c[1] < 200 * rays and rays < c[2] < 10 * rays         # ~59 inner nodes, ~2 objects per ray, not 10^6
+    total = torch.zeros_like(whole)
+    for first, count in ((0, 3), (3, 5)):
+        part = shard.SampleShardRenderer(scene, S, 0, 1, seed=1)
+        part.first, part.count = first, count
+        part.render()
+        torch.cuda.synchronize()
+        total += part.rgb_sum
+    assert torch.allclose(total, whole, rtol=1e-5, atol=1e-6)
+
+
+def test_c4_full_gather_is_independent_of_the_query_order(pkg):
+    """C4: 10^6 photons, one query per primary diffuse hit at 1920x1080 (~9*10^5), k = 100.  The estimate of a
+    query does not depend on which queries precede it (the carried bound only prunes), k = 50 and k = 100
+    estimate the same irradiance, the k-th distance grows with k, and every photon asked for is stored."""
+    import torch
+
+    W, H = 1920, 1080
+    scene = pkg.scenes.cornell(W, H, "cornell8d")
+    gmap = pkg.tracer.PhotonMap(1000000).build(scene, caustics=False, seed=1)
+    assert gmap.count() == 1000000 and gmap.emitted() > gmap.count()
+    ids, t, nrm, _ = scene.PrimaryHits()
+    hit = (ids >= 1) & (ids <= 5)
+    ys, xs = np.nonzero(hit)
+    c = scene.flat[0].cam
+    cam = np.array(c.origin)
+    u, v = (xs + 0.5) / W, (ys + 0.5) / H
+    D = np.array(c.lower_left)[None] + np.array(c.horizontal)[None] * u[:, None] + np.array(c.vertical)[None] * v[:, None] - cam[None]
+    P = (cam[None] + D * t[hit].astype(np.float64)[:, None]).astype(np.float32)
+    N = nrm[hit].astype(np.float32)
+    assert 8e5 < len(P) < 1e6
+    a = gmap.IrradianceEst(P, N, 0.0, 100)
+    assert np.isfinite(a).all() and (a >= 0).all() and (a.sum(1) > 0).mean() > 0.95
+    perm = np.random.RandomState(1).permutation(len(P))                      # image order destroyed: every bound is loose
+    b = gmap.IrradianceEst(P[perm], N[perm], 0.0, 100)
+    close = np.isclose(a[perm], b, rtol=1e-4, atol=1e-9).all(1)              # same photon set; FP32 sums in another order
+    assert close.mean() > 0.9999, close.mean()
+    half = gmap.IrradianceEst(P[::7], N[::7], 0.0, 50)
+    full = a[::7]
+    # k = 50 against k = 100 on the same surface: both estimate the same irradiance (within Monte Carlo spread)
+    m50, m100 = half.mean(0), full.mean(0)
+    assert np.allclose(m50, m100, rtol=0.05), (m50, m100)
+    # the squared k-th distance the gather reports (its workspace output)
+    lib = pkg._capi.load()
+    dP, dN = torch.from_numpy(P[::7].copy()).cuda(), torch.from_numpy(N[::7].copy()).cuda()
+    out = torch.empty_like(dP)
+    ws = torch.empty(int(lib.grt_photon_gather_workspace_bytes(len(dP))), dtype=torch.uint8, device="cuda")
+    rk = {}
+    for k in (50, 100):
+        pkg._capi.check(lib.grt_photon_gather_dev(gmap.handle, dP.data_ptr(), dN.data_ptr(), len(dP), 0.0, k, out.data_ptr(),
+                                                  ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        rk[k] = ws.view(torch.float32)[: len(dP)].clone()
+    assert (rk[50] <= rk[100]).all() and (rk[50] > 0).all()                  # the k-th distance grows with k
