@@ -140,3 +140,15 @@ def test_c4_full_gather_is_independent_of_the_query_order(pkg):
         torch.cuda.synchronize()
         rk[k] = ws.view(torch.float32)[: len(dP)].clone()
     assert (rk[50] <= rk[100]).all() and (rk[50] > 0).all()                  # the k-th distance grows with k
+
+
+def test_c4_full_sharded_build_equals_the_single_build(pkg, shard):
+    """C4 at 10^6 photons: the photon map built from emission slices (grt_photon_emit_dev + all-gather +
+    grt_photon_load_dev, here with one rank) holds the photons of grt_photon_build, bit for bit and in the
+    same order, and reports the same emission count."""
+    scene = pkg.scenes.cornell(64, 64, "cornell8d")
+    ref = pkg.tracer.PhotonMap(1000000).build(scene, caustics=False, seed=1)
+    one = shard.build_photon_map_sharded(scene, 1000000, False, 0, 1, seed=1)
+    assert one.count() == ref.count() == 1000000 and one.emitted() == ref.emitted()
+    for a, b in zip(one.read(), ref.read()):
+        assert (a == b).all()
