@@ -152,3 +152,33 @@ def test_c4_full_sharded_build_equals_the_single_build(pkg, shard):
     assert one.count() == ref.count() == 1000000 and one.emitted() == ref.emitted()
     for a, b in zip(one.read(), ref.read()):
         assert (a == b).all()
+
+
+def test_c4_ten_million_photons_knn_is_exact(pkg):
+    """C4's larger size: 10^7 photons (tree depth 18).  The squared k-th distance the gather reports for
+    256 queries equals a brute-force k-th smallest over ALL photons (torch on the GPU)."""
+    import torch
+
+    scene = pkg.scenes.cornell(64, 64, "cornell8d")
+    gmap = pkg.tracer.PhotonMap(10000000).build(scene, caustics=False, seed=1)
+    assert gmap.count() == 10000000
+    pos, pw, tp = gmap.read()
+    P = torch.from_numpy(pos).cuda()
+    rs = np.random.RandomState(4)
+    sel = rs.choice(len(pos), 256, replace=False)
+    Q = pos[sel] + rs.normal(scale=0.05, size=(256, 3)).astype(np.float32)   # near the surfaces, off the photons
+    Nq = np.tile(np.array([0.0, 0.0, 0.0], np.float32), (256, 1))
+    lib = pkg._capi.load()
+    dQ, dN = torch.from_numpy(Q).cuda(), torch.from_numpy(Nq).cuda()
+    out = torch.empty_like(dQ)
+    ws = torch.empty(int(lib.grt_photon_gather_workspace_bytes(256)), dtype=torch.uint8, device="cuda")
+    pkg._capi.check(lib.grt_photon_gather_dev(gmap.handle, dQ.data_ptr(), dN.data_ptr(), 256, 0.0, 100, out.data_ptr(), ws.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    rk2 = ws.view(torch.float32)[:256].cpu().numpy()
+    ref = np.empty(256, np.float32)
+    for i in range(0, 256, 32):                                              # 32 queries x 10^7 distances at a time
+        d = P[None, :, :] - dQ[i:i + 32, None, :]
+        d2 = torch.addcmul(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]), d[..., 2], d[..., 2])
+        ref[i:i + 32] = torch.topk(d2, 100, dim=1, largest=False).values[:, -1].cpu().numpy()
+    assert np.allclose(rk2, ref, rtol=1e-5), np.abs(rk2 / ref - 1).max()
