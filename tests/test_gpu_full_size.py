@@ -182,3 +182,57 @@ def test_c4_ten_million_photons_knn_is_exact(pkg):
         d2 = torch.addcmul(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]), d[..., 2], d[..., 2])
         ref[i:i + 32] = torch.topk(d2, 100, dim=1, largest=False).values[:, -1].cpu().numpy()
     assert np.allclose(rk2, ref, rtol=1e-5), np.abs(rk2 / ref - 1).max()
+
+
+def test_c5_million_spheres_hits_equal_a_brute_force_scan(pkg):
+    """C5's hierarchy at its full size (10^6 spheres, 20 levels, 16-bit grid): the object a pixel-centre
+    ray hits equals what the reference's loop over ALL objects finds (scene.go:169-181, evaluated in float64
+    with torch on the GPU for 1024 pixels inside the cloud)."""
+    import torch
+
+    W, H = 1920, 1080
+    flat = pkg.scenes.spheres_flat(1000000, W, H)
+    scene = pkg.tracer.Scene.from_flat(flat)
+    ids, t, _, _ = scene.PrimaryHits(0, 1)
+    prims = np.frombuffer(flat[1], dtype=pkg.tracer.PRIM_DTYPE)[: flat[2]]
+    c = flat[0].cam
+    rs = np.random.RandomState(8)
+    ys, xs = rs.randint(300, 780, 1024), rs.randint(560, 1360, 1024)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    O = torch.tensor(list(c.origin), **f64)
+    u, v = torch.tensor((xs + 0.5) / W, **f64), torch.tensor((ys + 0.5) / H, **f64)
+    D = (torch.tensor(list(c.lower_left), **f64)[None] + torch.tensor(list(c.horizontal), **f64)[None] * u[:, None]
+         + torch.tensor(list(c.vertical), **f64)[None] * v[:, None] - O[None])
+    sph = prims["kind"] == pkg.tracer.GRT_KIND_SPHERE
+    C = torch.tensor(prims["a"][sph], **f64)
+    R = torch.tensor(prims["radius"][sph], **f64)
+    sph_index = torch.tensor(np.nonzero(sph)[0], device="cuda")
+    bias, best_t, best_i = float(flat[0].bias), torch.full((1024,), float("inf"), **f64), torch.full((1024,), -1, dtype=torch.int64, device="cuda")
+    for k, (lo, hi) in enumerate(zip(prims["a"][~sph], prims["b"][~sph])):   # the two boxes come first in Scene.Objects
+        lo, hi = torch.tensor(lo, **f64), torch.tensor(hi, **f64)
+        n, f = (lo[None] - O[None]) / D, (hi[None] - O[None]) / D
+        t0, t1 = torch.minimum(n, f).max(1).values, torch.maximum(n, f).min(1).values
+        ok = (torch.minimum(best_t, t1) > torch.clamp(t0, min=bias)) & (t0 > 0)
+        best_t = torch.where(ok, t0, best_t)
+        best_i = torch.where(ok, torch.full_like(best_i, int(np.nonzero(~sph)[0][k])), best_i)
+    a = (D * D).sum(1)
+    for i in range(0, 1024, 64):                                             # 64 rays x 10^6 spheres at a time
+        oc = O[None, None, :] - C[None, :, :]
+        hb = (oc * D[i:i + 64, None, :]).sum(2)
+        cc = (oc * oc).sum(2) - (R * R)[None, :]
+        disc = hb * hb - a[i:i + 64, None] * cc
+        sq = torch.sqrt(torch.clamp(disc, min=0))
+        t1, t2 = (-hb - sq) / a[i:i + 64, None], (-hb + sq) / a[i:i + 64, None]
+        inf = torch.full_like(t1, float("inf"))
+        th = torch.where((disc >= 0) & (t1 > bias), t1, torch.where((disc >= 0) & (t2 > bias), t2, inf))
+        m = th.min(1)
+        closer = m.values < best_t[i:i + 64]                                 # strictly closer: later objects never win ties
+        best_t[i:i + 64] = torch.where(closer, m.values, best_t[i:i + 64])
+        best_i[i:i + 64] = torch.where(closer, sph_index[m.indices], best_i[i:i + 64])
+    ref_i, ref_t = best_i.cpu().numpy(), best_t.cpu().numpy()
+    got_i, got_t = ids[ys, xs], t[ys, xs]
+    assert (ref_i >= 2).mean() > 0.5                                         # most of these rays hit a sphere
+    same = got_i == ref_i
+    assert same.mean() > 0.998, same.mean()                                  # FP32 silhouettes (no float64 re-test on this path)
+    hit = same & (ref_i >= 0)
+    assert (np.abs(got_t[hit] - ref_t[hit]) / ref_t[hit]).max() < 1e-4
