@@ -236,3 +236,23 @@ def test_c5_million_spheres_hits_equal_a_brute_force_scan(pkg):
     assert same.mean() > 0.998, same.mean()                                  # FP32 silhouettes (no float64 re-test on this path)
     hit = same & (ref_i >= 0)
     assert (np.abs(got_t[hit] - ref_t[hit]) / ref_t[hit]).max() < 1e-4
+
+
+def test_c4_full_frame_photon_mapped_render_with_dark_photons_is_the_plain_render(pkg):
+    """Photon-mapped trace() (scene.go:308-320) at 1920x1080 x 16 spp: with maps whose photons carry no
+    power the photon term is zero, so the frame must be the plain path-traced frame (another grouping of
+    the FP32 sums: batches of 8 samples instead of chunks); with real maps it can only add light."""
+    W, H, S = 1920, 1080, 16
+    scene = pkg.scenes.cornell(W, H, "cornell8d")
+    plain = scene.RenderAccum(S, seed=1)
+    rs = np.random.RandomState(2)
+    pos = rs.uniform(0, 555, (5000, 3)).astype(np.float32)
+    dark = pkg.tracer.PhotonMap.load(pos, np.zeros((5000, 3), np.float32), rs.randint(0, 256, (5000, 2)).astype(np.uint8))
+    scene.globalPmap, scene.causticPmap = dark, dark
+    a = scene.RenderAccumPhotonMapped(S, seed=1)
+    assert np.allclose(a, plain, rtol=1e-5, atol=1e-5)
+    scene.globalPmap = pkg.tracer.PhotonMap(1000000).build(scene, caustics=False, seed=1)
+    scene.causticPmap = pkg.tracer.PhotonMap(500000).build(scene, caustics=True, seed=1)
+    b = scene.RenderAccumPhotonMapped(S, seed=1)
+    gain = float(b.mean() / plain.mean())
+    assert (b >= plain - 1e-4).all() and 1.0005 < gain < 1.5, gain           # the maps add light, a little (powers scale with 1000 / max)
