@@ -161,3 +161,35 @@ def test_tile_culling_changes_no_pixel(pkg, monkeypatch):
     T = pkg.tracer
     away = T.NewScene(64, 64, T.NewCamera(pkg.scenes.EYE, (278.0, 278.0, -2000.0), pkg.scenes.VUP, 40.0, 1.0), pkg.scenes.cornell_objects())
     assert (away.RenderAccum(4, seed=1) == 0).all() and away.last_ray_count() == 0
+
+
+def test_empty_and_minimal_inputs(pkg, ob):
+    """Edge sizes: a scene without objects (every ray misses: black, scene.go:244-250), a scene that is only
+    a light (a path that reaches it returns Color * Emittance, scene.go:277-279, exactly), a 1x1 frame, one
+    sample — through the render, the per-sample and the parity entry points, and against the oracle."""
+    T = pkg.tracer
+    cam = pkg.scenes.cornell_camera(1.0)
+    empty = T.NewScene(40, 24, pkg.scenes.cornell_camera(40 / 24), [])
+    assert (empty.RenderAccum(3, seed=1) == 0).all()
+    px = np.full(24 * 160, 0xAB, np.uint8)
+    empty.Render(px, 160, 2, seed=1)
+    assert (px.reshape(24, 40, 4)[..., :3] == 0).all() and (px.reshape(24, 40, 4)[..., 3] == 0xAB).all()
+    ids, t, _, _ = empty.PrimaryHits()
+    assert (ids == -1).all()
+    rgb, nr = empty.TraceSamples(np.array([[0, 0], [39, 23]], np.int32), 2, seed=1)
+    assert (rgb == 0).all() and (nr == 1).all()                              # one intersect() call per path, no hit
+    assert (ob.OracleScene(empty.flat).RenderAccum(3, seed=1) == 0).all()
+
+    light = pkg.scenes.cornell_objects()[0]                                   # Color 0.2, Emittance 10
+    only = T.NewScene(32, 32, cam, [T.NewAABB((-2000, -2000, 100), (3000, 3000, 101), light.Mat)])
+    f = only.RenderAccum(5, seed=2)
+    assert (f == np.float32(5 * 0.2 * 10)).all()                             # the slab fills the view: 5 samples x 2.0
+    assert np.allclose(ob.OracleScene(only.flat).RenderAccum(5, seed=2), f)
+
+    one = T.NewScene(1, 1, cam, pkg.scenes.cornell_objects())
+    a = one.RenderAccum(1, seed=3)
+    assert a.shape == (1, 1, 3) and np.isfinite(a).all()
+    rgb, nr = one.TraceSamples(np.array([[0, 0]], np.int32), 64, seed=3)
+    orgb, onr = ob.OracleScene(one.flat).TraceSamples(np.array([[0, 0]], np.int32), 64, seed=3)
+    assert (nr == onr).mean() > 0.95 and np.allclose(rgb.mean((0, 1)), orgb.mean((0, 1)), rtol=0.05, atol=1e-3)
+    assert np.allclose(one.RenderAccum(64, seed=3)[0, 0], rgb.sum((0, 1)), rtol=1e-5)   # Render = the sum of its samples
