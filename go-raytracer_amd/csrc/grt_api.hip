@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <future>
 #include <cmath>
 #include <cstdio>
@@ -131,46 +132,72 @@ const grt_scene_desc* grt_scene_desc_of(const grt_scene* s) { return &s->d; }
 // Median split on the axis of largest centroid extent down to leaves of <= GRT_BVH_LEAF
 // objects: balanced, so the traversal stack depth is log2(n / leaf) + 1 (checked against
 // GRT_BVH_STACK).  Built on the host from the FP32 records the kernels test.
+// GRT_TIMING=1: phases of scene staging on stderr (diagnostics)
+struct StageClock {
+  const bool on = getenv("GRT_TIMING") != nullptr;
+  double t = now();
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void lap(const char* what) {
+    if (!on) return;
+    const double u = now();
+    fprintf(stderr, "[grt stage] %-28s %7.1f ms\n", what, (u - t) * 1e3);
+    t = u;
+  }
+};
+
+// fn(i0, i1) over [0, n) cut into one range per worker (host-side passes over 10^6 objects)
+template <class F>
+static void parallel_ranges(int n, F fn) {
+  const int workers = n < 65536 ? 1 : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (workers == 1) return fn(0, n);
+  std::vector<std::future<void>> fs;
+  for (int w = 0; w < workers; ++w) {
+    const int i0 = (int)((long long)n * w / workers), i1 = (int)((long long)n * (w + 1) / workers);
+    fs.push_back(std::async(std::launch::async, [=] { fn(i0, i1); }));
+  }
+  for (auto& f : fs) f.get();
+}
+
+struct BvhItem {
+  float k[3];  // lo + hi of the object's box per axis (twice its centre): the split key
+  int idx;     // object index
+};
 struct BvhBuild {
-  const std::vector<float4>* hp;   // the staged object records (2 per object)
   std::vector<float> lo, hi;       // padded object boxes, 3 per object
-  std::vector<int> order;          // slot -> object index
+  std::vector<BvhItem> items;      // slot -> object, partitioned in place (contiguous: every pass of the build streams)
+  std::vector<int> order;          // slot -> object index, once the build is done
   std::vector<float4> nodes;
   std::atomic<int> n_nodes{0};
-  int max_depth = 0;
+  std::atomic<int> max_depth{0};
   int leaf = GRT_BVH_LEAF;       // objects per leaf (<= 7: the count lives in 3 bits of the reference)
-  std::mutex mu;
 };
 static void bvh_range_box(const BvhBuild& B, int a, int b, float* lo, float* hi) {
   for (int c = 0; c < 3; ++c) lo[c] = 3e38f, hi[c] = -3e38f;
   for (int i = a; i < b; ++i)
     for (int c = 0; c < 3; ++c) {
-      lo[c] = std::min(lo[c], B.lo[3 * (size_t)B.order[i] + c]);
-      hi[c] = std::max(hi[c], B.hi[3 * (size_t)B.order[i] + c]);
+      lo[c] = std::min(lo[c], B.lo[3 * (size_t)B.items[i].idx + c]);
+      hi[c] = std::max(hi[c], B.hi[3 * (size_t)B.items[i].idx + c]);
     }
 }
-// Returns the reference of the subtree over order[a, b) and its box.
+// Returns the reference of the subtree over items[a, b) and its box (the union of its children's).
 static int bvh_build(BvhBuild& B, int a, int b, float* lo, float* hi, int depth, int par_depth) {
-  bvh_range_box(B, a, b, lo, hi);
   if (b - a <= B.leaf) {
-    std::lock_guard<std::mutex> g(B.mu);
-    B.max_depth = std::max(B.max_depth, depth);
+    bvh_range_box(B, a, b, lo, hi);
+    int cur = B.max_depth.load(std::memory_order_relaxed);  // (a lock here was taken once per leaf: 10^6 times)
+    while (depth > cur && !B.max_depth.compare_exchange_weak(cur, depth, std::memory_order_relaxed)) {
+    }
     return ~((a << 3) | (b - a));
   }
   float cl[3] = {3e38f, 3e38f, 3e38f}, ch[3] = {-3e38f, -3e38f, -3e38f};
   for (int i = a; i < b; ++i)
-    for (int c = 0; c < 3; ++c) {
-      const float m = 0.5f * (B.lo[3 * (size_t)B.order[i] + c] + B.hi[3 * (size_t)B.order[i] + c]);
-      cl[c] = std::min(cl[c], m), ch[c] = std::max(ch[c], m);
-    }
+    for (int c = 0; c < 3; ++c) cl[c] = std::min(cl[c], B.items[i].k[c]), ch[c] = std::max(ch[c], B.items[i].k[c]);
   int ax = 0;
   if (ch[1] - cl[1] > ch[ax] - cl[ax]) ax = 1;
   if (ch[2] - cl[2] > ch[ax] - cl[ax]) ax = 2;
   const int mid = a + (b - a) / 2;
-  std::nth_element(B.order.begin() + a, B.order.begin() + mid, B.order.begin() + b, [&](int x, int y) {
-    const float cx = B.lo[3 * (size_t)x + ax] + B.hi[3 * (size_t)x + ax], cy = B.lo[3 * (size_t)y + ax] + B.hi[3 * (size_t)y + ax];
-    return cx < cy || (cx == cy && x < y);
-  });
+  // a strict total order (ties by object index): the two halves are the same sets whatever nth_element does inside
+  std::nth_element(B.items.begin() + a, B.items.begin() + mid, B.items.begin() + b,
+                   [ax](const BvhItem& x, const BvhItem& y) { return x.k[ax] < y.k[ax] || (x.k[ax] == y.k[ax] && x.idx < y.idx); });
   const int me = B.n_nodes.fetch_add(1);
   float l0[3], h0[3], l1[3], h1[3];
   int r0, r1;
@@ -187,29 +214,34 @@ static int bvh_build(BvhBuild& B, int a, int b, float* lo, float* hi, int depth,
   n[1] = make_float4(h0[0], h0[1], h0[2], 0.0f);
   n[2] = make_float4(l1[0], l1[1], l1[2], __builtin_bit_cast(float, r1));
   n[3] = make_float4(h1[0], h1[1], h1[2], 0.0f);
+  for (int c = 0; c < 3; ++c) lo[c] = std::min(l0[c], l1[c]), hi[c] = std::max(h0[c], h1[c]);
   return me;
 }
 
 static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceScene& d) {
   const int n = (int)s->prims.size();
+  StageClock clk;
   BvhBuild B;
-  B.hp = &hp;
-  B.lo.resize(3 * (size_t)n), B.hi.resize(3 * (size_t)n), B.order.resize(n);
+  B.lo.resize(3 * (size_t)n), B.hi.resize(3 * (size_t)n), B.items.resize(n), B.order.resize(n);
   const float eye_r = (float)std::max({std::fabs(s->d.cam.origin[0]), std::fabs(s->d.cam.origin[1]), std::fabs(s->d.cam.origin[2])});
-  for (int i = 0; i < n; ++i) {
-    const float4 pa = hp[2 * (size_t)i], pb = hp[2 * (size_t)i + 1];
-    const bool box = (__builtin_bit_cast(int, pb.w) & 1) != 0;
-    const float c[3] = {pa.x, pa.y, pa.z}, e[3] = {pb.x, pb.y, pb.z};
-    for (int k = 0; k < 3; ++k) {
-      float l = box ? std::min(c[k], e[k]) : c[k] - std::fabs(pa.w);
-      float h = box ? std::max(c[k], e[k]) : c[k] + std::fabs(pa.w);
-      // padding: the slab arithmetic of a box around a sphere and sphere_hit32 round differently, both
-      // with absolute errors that grow with the coordinates of the ray origin (the eye for primary rays)
-      const float pad = 4e-6f * (std::fabs(l) + std::fabs(h) + (h - l)) + 1e-6f * eye_r + 1e-30f;
-      B.lo[3 * (size_t)i + k] = l - pad, B.hi[3 * (size_t)i + k] = h + pad;
+  parallel_ranges(n, [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+      const float4 pa = hp[2 * (size_t)i], pb = hp[2 * (size_t)i + 1];
+      const bool box = (__builtin_bit_cast(int, pb.w) & 1) != 0;
+      const float c[3] = {pa.x, pa.y, pa.z}, e[3] = {pb.x, pb.y, pb.z};
+      for (int k = 0; k < 3; ++k) {
+        float l = box ? std::min(c[k], e[k]) : c[k] - std::fabs(pa.w);
+        float h = box ? std::max(c[k], e[k]) : c[k] + std::fabs(pa.w);
+        // padding: the slab arithmetic of a box around a sphere and sphere_hit32 round differently, both
+        // with absolute errors that grow with the coordinates of the ray origin (the eye for primary rays)
+        const float pad = 4e-6f * (std::fabs(l) + std::fabs(h) + (h - l)) + 1e-6f * eye_r + 1e-30f;
+        B.lo[3 * (size_t)i + k] = l - pad, B.hi[3 * (size_t)i + k] = h + pad;
+        B.items[i].k[k] = (l - pad) + (h + pad);
+      }
+      B.items[i].idx = i;
     }
-    B.order[i] = i;
-  }
+  });
+  clk.lap("hierarchy: object boxes");
   B.nodes.resize(4 * (size_t)std::max(1, n));
   float lo[3], hi[3];
   // Leaves of 2 objects walk fastest (measured at C5); deeper scenes take larger leaves so that the
@@ -226,21 +258,24 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   } else {
     const int root = bvh_build(B, 0, n, lo, hi, 0, 4);
     if (root != 0) return grt_fail(GRT_EINVAL, "internal: BVH root is node %d", root);
-    if (B.max_depth + 1 > GRT_BVH_STACK)
-      return grt_fail(GRT_ELIMIT, "grt_scene: hierarchy depth %d exceeds the traversal stack (%d)", B.max_depth, GRT_BVH_STACK);
+    if (B.max_depth.load() + 1 > GRT_BVH_STACK)
+      return grt_fail(GRT_ELIMIT, "grt_scene: hierarchy depth %d exceeds the traversal stack (%d)", B.max_depth.load(), GRT_BVH_STACK);
   }
+  clk.lap("hierarchy: median splits");
   // leaf-order object records; the last word becomes index << 3 | the three flag bits (grt_bvh.h)
   std::vector<float4> bp(2 * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    const int o = B.order[i];
-    float4 pb = hp[2 * (size_t)o + 1];
-    pb.w = __builtin_bit_cast(float, (uint32_t)o << 3 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 7u));  // kind, emissive, transparent
-    bp[2 * (size_t)i] = hp[2 * (size_t)o], bp[2 * (size_t)i + 1] = pb;
-  }
+  parallel_ranges(n, [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+      const int o = B.order[i] = B.items[i].idx;
+      float4 pb = hp[2 * (size_t)o + 1];
+      pb.w = __builtin_bit_cast(float, (uint32_t)o << 3 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 7u));  // kind, emissive, transparent
+      bp[2 * (size_t)i] = hp[2 * (size_t)o], bp[2 * (size_t)i + 1] = pb;
+    }
+  });
   // The 16-bit grid: the scene's bounds widened by 1/1024 on each side, 65535 cells per axis.  Boxes
   // round outward and take one more cell, which covers the FP32 rounding of the slab arithmetic in
   // grid coordinates (< 0.01 cell: coordinates <= 65535 at 2^-24 relative).
-  bvh_range_box(B, 0, n, lo, hi);
+  // (lo, hi: the root box, left by the build above)
   float gmin[3], gs[3];
   for (int c = 0; c < 3; ++c) {
     const double ext = std::max((double)hi[c] - (double)lo[c], 1e-30 + 1e-6 * (std::fabs((double)hi[c]) + std::fabs((double)lo[c])));
@@ -251,7 +286,8 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     gmin[c] = (float)((double)lo[c] - std::max(ext / 1024.0, 4.0 * (double)gs[c]));
     d.bvh_grid[c] = gmin[c], d.bvh_grid[3 + c] = gs[c], d.bvh_grid[6 + c] = 1.0f / gs[c];
   }
-  d.bvh_depth = B.max_depth;
+  clk.lap("hierarchy: leaf records, grid");
+  d.bvh_depth = B.max_depth.load();
   // Memory order of the nodes: the inner children of a node are neighbours (one 64-byte pair, even
   // slot first), followed by the pair of the first child's children, then the rest of the first
   // child's subtree, then the second child's.  A 128-byte cache line so holds a pair of siblings and
@@ -277,10 +313,12 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
       if (c0 >= 0) todo.push_back(c0);  // walked first
     }
   }
+  clk.lap("hierarchy: node order");
   const size_t n_nodes = node_at.size();
   std::vector<uint4> qn(2 * n_nodes, make_uint4(0, 0, 0, (uint32_t)~0));
-  bool grid_ok = true;
-  for (size_t k = 0; k < 2 * n_nodes; ++k) {
+  std::atomic<bool> grid_ok{true};
+  parallel_ranges((int)(2 * n_nodes), [&](int k0, int k1) {
+  for (size_t k = (size_t)k0; k < (size_t)k1; ++k) {
     if (node_at[k / 2] < 0) continue;  // pad: two empty leaves, never referenced
     const size_t src = 2 * (size_t)node_at[k / 2] + (k & 1);
     float4 l = B.nodes[2 * src];
@@ -300,11 +338,14 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     }
     qn[k] = make_uint4(ql[0] | ql[1] << 16, ql[2] | qh[0] << 16, qh[1] | qh[2] << 16, (uint32_t)__builtin_bit_cast(int, l.w));
   }
-  if (!grid_ok) return grt_fail(GRT_EINVAL, "internal: hierarchy box outside its grid");
+  });
+  clk.lap("hierarchy: quantise");
+  if (!grid_ok.load()) return grt_fail(GRT_EINVAL, "internal: hierarchy box outside its grid");
   GRT_HIP(hipMalloc(&d.bvh_nodes, qn.size() * sizeof(uint4)));
   GRT_HIP(hipMalloc(&d.bvh_prims, bp.size() * sizeof(float4)));
   GRT_HIP(hipMemcpy(d.bvh_nodes, qn.data(), qn.size() * sizeof(uint4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(d.bvh_prims, bp.data(), bp.size() * sizeof(float4), hipMemcpyHostToDevice));
+  clk.lap("hierarchy: upload");
   return GRT_OK;
 }
 
@@ -378,6 +419,7 @@ static int stage(grt_scene* s, DeviceScene& out) {
     out = it->second;
     return GRT_OK;
   }
+  StageClock clk;
   const size_t np = s->prims.size(), nm = s->mats.size(), nl = s->lights.size();
   // object and material tables are padded to GRT_FAST_PRIMS records (never-hit spheres / zero materials) so the register-resident kernel loads them whole
   std::vector<float4> hp(2 * std::max<size_t>(np, GRT_FAST_PRIMS)), hm(2 * std::max<size_t>(nm, GRT_FAST_PRIMS)),
@@ -387,21 +429,23 @@ static int stage(grt_scene* s, DeviceScene& out) {
     hp[2 * i + 1] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
   }
   std::vector<double> h64(8 * std::max<size_t>(np, 1));
-  for (size_t i = 0; i < np; ++i) {
-    const grt_prim& p = s->prims[i];
-    const grt_material& m = s->mats[p.material];
-    int bits = (p.kind == GRT_KIND_AABB ? 1 : 0) | (m.emittance > 0 ? 2 : 0) | (m.transparent ? 4 : 0) | (p.material << 8);
-    float w;
-    memcpy(&w, &bits, 4);
-    hp[2 * i] = make_float4((float)p.a[0], (float)p.a[1], (float)p.a[2], (float)p.radius);
-    if (p.kind == GRT_KIND_AABB)
-      hp[2 * i + 1] = make_float4((float)p.b[0], (float)p.b[1], (float)p.b[2], w);
-    else
-      hp[2 * i + 1] = make_float4((float)(p.radius * p.radius), 0.0f, 0.0f, w);
-    double* q = &h64[8 * i];
-    q[0] = p.a[0], q[1] = p.a[1], q[2] = p.a[2], q[3] = p.b[0], q[4] = p.b[1], q[5] = p.b[2];
-    q[6] = p.radius, q[7] = p.kind == GRT_KIND_AABB ? 1.0 : 0.0;
-  }
+  parallel_ranges((int)np, [&](int i0, int i1) {
+    for (size_t i = (size_t)i0; i < (size_t)i1; ++i) {
+      const grt_prim& p = s->prims[i];
+      const grt_material& m = s->mats[p.material];
+      int bits = (p.kind == GRT_KIND_AABB ? 1 : 0) | (m.emittance > 0 ? 2 : 0) | (m.transparent ? 4 : 0) | (p.material << 8);
+      float w;
+      memcpy(&w, &bits, 4);
+      hp[2 * i] = make_float4((float)p.a[0], (float)p.a[1], (float)p.a[2], (float)p.radius);
+      if (p.kind == GRT_KIND_AABB)
+        hp[2 * i + 1] = make_float4((float)p.b[0], (float)p.b[1], (float)p.b[2], w);
+      else
+        hp[2 * i + 1] = make_float4((float)(p.radius * p.radius), 0.0f, 0.0f, w);
+      double* q = &h64[8 * i];
+      q[0] = p.a[0], q[1] = p.a[1], q[2] = p.a[2], q[3] = p.b[0], q[4] = p.b[1], q[5] = p.b[2];
+      q[6] = p.radius, q[7] = p.kind == GRT_KIND_AABB ? 1.0 : 0.0;
+    }
+  });
   for (size_t i = 0; i < nm; ++i) {
     const grt_material& m = s->mats[i];
     int flags = (m.transparent ? GRT_MAT_TRANSPARENT : 0) | (m.lambert ? GRT_MAT_LAMBERT : 0) | (m.normal ? GRT_MAT_NORMAL : 0);
@@ -418,6 +462,7 @@ static int stage(grt_scene* s, DeviceScene& out) {
     hl[2 * k] = make_float4((float)pos[0], (float)pos[1], (float)pos[2], (float)s->lights[k]);
     hl[2 * k + 1] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], __builtin_bit_cast(float, (int)s->lights[k]));
   }
+  clk.lap("records (FP32 + FP64)");
   DeviceScene d;
   auto upload = [&]() -> int {
     GRT_HIP(hipMalloc(&d.prims, hp.size() * sizeof(float4)));
@@ -428,13 +473,16 @@ static int stage(grt_scene* s, DeviceScene& out) {
     GRT_HIP(hipMemcpy(d.mats, hm.data(), hm.size() * sizeof(float4), hipMemcpyHostToDevice));
     GRT_HIP(hipMemcpy(d.lights, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
     GRT_HIP(hipMemcpy(d.prims64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice));
+    clk.lap("upload");
     if (s->use_bvh) {
       int rc = stage_bvh(s, hp, d);
       if (rc) return rc;
     }
+    clk.t = StageClock::now();
     const std::vector<uint8_t> live = cull_tiles(s);
     GRT_HIP(hipMalloc(&d.tile_live, live.size()));
     GRT_HIP(hipMemcpy(d.tile_live, live.data(), live.size(), hipMemcpyHostToDevice));
+    clk.lap("tile culling");
     return GRT_OK;
   };
   const int rc = upload();
