@@ -11,7 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,14 +39,30 @@ int grt_fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+
+// Every int-returning entry point is a function-try-block that ends here: a C++ exception (a vector
+// that cannot grow for 10^7 objects, a thread that cannot start) must not unwind into a C or Go caller.
+int grt_fail_exception(const char* entry_point) {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    return grt_fail(GRT_EHOST, "%s: out of host memory", entry_point);
+  } catch (const std::exception& e) {
+    return grt_fail(GRT_EHOST, "%s: %s", entry_point, e.what());
+  } catch (...) {
+    return grt_fail(GRT_EHOST, "%s: unknown C++ exception", entry_point);
+  }
+}
 GRT_API const char* grt_last_error(void) { return g_err.c_str(); }
 GRT_API const char* grt_version(void) { return "grt-hip 0.1 (gfx950)"; }
 GRT_API uint64_t grt_last_ray_count(void) { return g_last_rays; }
 GRT_API double grt_last_kernel_ms(void) { return g_last_ms; }
-GRT_API int grt_device_count(void) {
+GRT_API int grt_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+} catch (...) {
+  return grt_fail_exception("grt_device_count");
 }
 GRT_API double grt_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
   return grt_rng_draw64(grt_rng_path_key(grt_rng_pixel_key(grt_rng_seed32(seed), pixel), sample), dim);
@@ -72,7 +91,7 @@ static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_
 }
 
 GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, int32_t n_prims,
-                             const grt_material* mats, int32_t n_mats, grt_scene** out) {
+                             const grt_material* mats, int32_t n_mats, grt_scene** out) try {
   if (!out) return grt_fail(GRT_EINVAL, "grt_scene_create: out is NULL");
   int rc = validate_scene(desc, prims, n_prims, mats, n_mats);
   if (rc) return rc;
@@ -83,7 +102,8 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   }
   const bool bvh_forced = n_prims > GRT_MAX_LINEAR_PRIMS || (desc->accel == GRT_ACCEL_BVH && n_prims > 0);
   const bool use_bvh = bvh_forced || (desc->accel == GRT_ACCEL_AUTO && n_prims > GRT_BVH_AUTO_PRIMS);
-  grt_scene* s = new grt_scene;
+  std::unique_ptr<grt_scene> owner(new grt_scene);  // released to the caller only when everything below has succeeded
+  grt_scene* s = owner.get();
   s->d = *desc;
   s->use_bvh = use_bvh;
   s->bvh_forced = bvh_forced;
@@ -98,8 +118,10 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
     }
     if (m.transparent) s->tobjects.push_back(i);
   }
-  *out = s;
+  *out = owner.release();
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_scene_create");
 }
 
 // hipFree(nullptr) is a no-op: a partly staged scene is released the same way.
@@ -670,18 +692,22 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
 
 GRT_API int grt_render_accum_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
                                  float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count,
-                                 void* stream) {
+                                 void* stream) try {
   return grt_render_dev_internal(s, o, shard, n_shards, 0, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream,
                                  nullptr, nullptr, nullptr, 0);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_dev");
 }
 
 // Sample-range sharding: the whole frame, samples [sample_first, sample_first + samples) of every
 // pixel.  The RNG is keyed by the absolute sample index, so the ranks' frames add up to the frame
 // a single device renders (up to the order of the FP32 additions across ranks).
 GRT_API int grt_render_accum_samples_dev(grt_scene* s, const grt_opts* o, int32_t sample_first, int32_t samples, float* d_rgb_sum,
-                                         void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
+                                         void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) try {
   return grt_render_dev_internal(s, o, 0, 1, sample_first, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream,
                                  nullptr, nullptr, nullptr, 0);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_samples_dev");
 }
 
 // total (+)= frame + photon term of one batch (k_pm_accumulate); used by grt_photon.hip
@@ -694,7 +720,7 @@ int grt_pm_accumulate_internal(const float* frame, const float* qpos, const floa
 }
 
 GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows, int32_t samples, uint8_t* d_bgrx,
-                            int32_t pitch, void* stream) {
+                            int32_t pitch, void* stream) try {
   if (!d_rgb_sum || !d_bgrx || width <= 0 || rows < 0 || samples <= 0) return grt_fail(GRT_EINVAL, "grt_tonemap_dev: bad argument");
   const int bpp = pitch / width;  // scene.go:85
   if (bpp < 3) return grt_fail(GRT_EINVAL, "grt_tonemap_dev: pitch %d gives %d bytes per pixel (<3)", pitch, bpp);
@@ -705,6 +731,8 @@ GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows,
                      1.0f / (float)samples, d_bgrx, pitch, bpp);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_tonemap_dev");
 }
 
 // ---- host-buffer entry points ------------------------------------------------------------
@@ -826,15 +854,19 @@ static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_
   return GRT_OK;
 }
 
-GRT_API int grt_render(grt_scene* s, const grt_opts* o, uint8_t* pixels, int32_t pitch, int32_t samples) {
+GRT_API int grt_render(grt_scene* s, const grt_opts* o, uint8_t* pixels, int32_t pitch, int32_t samples) try {
   if (!s || !pixels) return grt_fail(GRT_EINVAL, "grt_render: NULL scene or pixels");
   if (pitch / s->d.width < 3) return grt_fail(GRT_EINVAL, "grt_render: pitch %d gives %d bytes per pixel (<3)", pitch, pitch / s->d.width);
   return render_host(s, o, samples, nullptr, pixels, pitch);
+} catch (...) {
+  return grt_fail_exception("grt_render");
 }
 
-GRT_API int grt_render_accum(grt_scene* s, const grt_opts* o, float* rgb_sum, int32_t samples) {
+GRT_API int grt_render_accum(grt_scene* s, const grt_opts* o, float* rgb_sum, int32_t samples) try {
   if (!s || !rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum: NULL scene or output");
   return render_host(s, o, samples, rgb_sum, nullptr, 0);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum");
 }
 
 static int use_device(const grt_opts* o) {
@@ -847,7 +879,7 @@ static int use_device(const grt_opts* o) {
 }
 
 GRT_API int grt_trace_samples(grt_scene* s, const grt_opts* o, const int32_t* pixel_xy, int32_t n_pixels, int32_t samples,
-                              float* rgb, int32_t* n_rays) {
+                              float* rgb, int32_t* n_rays) try {
   if (!s || !pixel_xy || !rgb || n_pixels < 0 || samples < 0) return grt_fail(GRT_EINVAL, "grt_trace_samples: bad argument");
   for (int i = 0; i < n_pixels; ++i)
     if (pixel_xy[2 * i] < 0 || pixel_xy[2 * i] >= s->d.width || pixel_xy[2 * i + 1] < 0 || pixel_xy[2 * i + 1] >= s->d.height)
@@ -893,12 +925,14 @@ GRT_API int grt_trace_samples(grt_scene* s, const grt_opts* o, const int32_t* pi
   (void)hipFree(d_rgb);
   (void)hipFree(d_nr);
   return rc;
+} catch (...) {
+  return grt_fail_exception("grt_trace_samples");
 }
 
 // flags bit 8..9 of opts->flags select the debug mode of the parity kernel:
 // 0 = FP32 + FP64 re-test of ambiguous lanes (default), 1 = FP32 only, 2 = FP64 only.
 GRT_API int grt_primary_hits(grt_scene* s, const grt_opts* o, int32_t jitter_mode, int32_t* id, float* t, float* normal_xyz,
-                             uint64_t* fallback_lanes) {
+                             uint64_t* fallback_lanes) try {
   if (!s || !id || !t || !normal_xyz) return grt_fail(GRT_EINVAL, "grt_primary_hits: NULL argument");
   if (jitter_mode != GRT_JITTER_CENTER && jitter_mode != GRT_JITTER_RNG)
     return grt_fail(GRT_EINVAL, "grt_primary_hits: unknown jitter mode %d", jitter_mode);
@@ -950,9 +984,11 @@ GRT_API int grt_primary_hits(grt_scene* s, const grt_opts* o, int32_t jitter_mod
   (void)hipFree(d_n);
   (void)hipFree(d_fb);
   return rc;
+} catch (...) {
+  return grt_fail_exception("grt_primary_hits");
 }
 
-GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t samples, uint32_t* d_checksum, void* stream) {
+GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t samples, uint32_t* d_checksum, void* stream) try {
   if (!s || !d_checksum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_primary_sweep_dev: bad argument");
   KScene ks;
   int rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
@@ -972,4 +1008,6 @@ GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t sampl
                        d_checksum);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_primary_sweep_dev");
 }

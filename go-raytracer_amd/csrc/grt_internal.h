@@ -17,6 +17,7 @@
 #define GRT_MAX_PRIMS (1 << 26)
 
 int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int grt_fail_exception(const char* entry_point);  // inside a catch (...): the current exception as GRT_EHOST + message
 
 #define GRT_HIP(expr)                                                                   \
   do {                                                                                  \

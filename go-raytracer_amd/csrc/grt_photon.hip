@@ -431,7 +431,7 @@ static int pick_device(const grt_opts* o, int* dev) {
   return GRT_OK;
 }
 
-GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) {
+GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) try {
   if (!s || !out || max_photons <= 0) return grt_fail(GRT_EINVAL, "grt_photon_build: bad argument");
   if (s->lights.empty()) return grt_fail(GRT_EINVAL, "grt_photon_build: the scene has no light (Emittance > 0)");
   int dev;
@@ -528,10 +528,12 @@ GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photon
   }
   *out = pm;
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_photon_build");
 }
 
 GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* power, const uint8_t* theta_phi, int32_t n,
-                            grt_pmap** out) {
+                            grt_pmap** out) try {
   if (!pos || !power || !theta_phi || n < 0 || !out) return grt_fail(GRT_EINVAL, "grt_photon_load: bad argument");
   int dev;
   int rc = pick_device(o, &dev);
@@ -561,6 +563,8 @@ GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* po
   }
   *out = pm;
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_photon_load");
 }
 
 // ---- emission slices + build from device arrays (photon-build sharding) -------
@@ -605,7 +609,7 @@ GRT_API int32_t grt_scene_light_share(const grt_scene* s, int32_t k) {
 
 GRT_API int grt_photon_emit_dev(grt_scene* s, const grt_opts* o, int32_t caustics, int32_t light, uint64_t first, int32_t count,
                                 float* d_pos4, float* d_pow4, int32_t* d_stored, void* d_workspace, uint64_t workspace_bytes,
-                                void* stream) {
+                                void* stream) try {
   if (!s || !d_pos4 || !d_pow4 || !d_stored || count <= 0) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: bad argument");
   if (light < 0 || light >= (int)s->lights.size()) return grt_fail(GRT_EINVAL, "grt_photon_emit_dev: light %d of %zu", light, s->lights.size());
   if (!d_workspace || workspace_bytes < grt_photon_emit_workspace_bytes(count))
@@ -636,10 +640,12 @@ GRT_API int grt_photon_emit_dev(grt_scene* s, const grt_opts* o, int32_t caustic
                      (float4*)d_pow4, d_stored);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_photon_emit_dev");
 }
 
 GRT_API int grt_photon_load_dev(const grt_opts* o, const float* d_pos4, const float* d_pow4, int32_t n, float power_scale,
-                                uint64_t emitted, grt_pmap** out) {
+                                uint64_t emitted, grt_pmap** out) try {
   if (n < 0 || !out || (n > 0 && (!d_pos4 || !d_pow4))) return grt_fail(GRT_EINVAL, "grt_photon_load_dev: bad argument");
   int dev;
   int rc = pick_device(o, &dev);
@@ -663,12 +669,14 @@ GRT_API int grt_photon_load_dev(const grt_opts* o, const float* d_pos4, const fl
   }
   *out = pm;
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_photon_load_dev");
 }
 
 GRT_API int32_t grt_photon_count(const grt_pmap* pm) { return pm ? pm->n : 0; }
 GRT_API uint64_t grt_photon_emitted(const grt_pmap* pm) { return pm ? pm->emitted : 0; }
 
-GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_t* theta_phi) {
+GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_t* theta_phi) try {
   if (!pm) return grt_fail(GRT_EINVAL, "grt_photon_read: NULL map");
   GRT_HIP(hipSetDevice(pm->device));
   const size_t n = (size_t)pm->n;
@@ -687,6 +695,8 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
     if (theta_phi) theta_phi[2 * d] = (uint8_t)(bits >> 8), theta_phi[2 * d + 1] = (uint8_t)(bits >> 16);
   }
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_photon_read");
 }
 
 GRT_API void grt_photon_free(grt_pmap* pm) {
@@ -1191,15 +1201,17 @@ static int gather_check(const grt_pmap* pm, const void* a, const void* b, const 
 // it receives the squared distance of each query's k-th nearest photon (+inf: fewer than k
 // photons in reach, -1: none).
 GRT_API int grt_photon_gather_dev(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int32_t n, float radius, int32_t k,
-                                  float* d_irrad, void* d_workspace, void* stream) {
+                                  float* d_irrad, void* d_workspace, void* stream) try {
   int rc = gather_check(pm, d_pos, d_nrm, d_irrad, n, k);
   if (rc) return rc;
   if (n == 0) return GRT_OK;
   return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream);
+} catch (...) {
+  return grt_fail_exception("grt_photon_gather_dev");
 }
 
 GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float* nrm, int32_t n, float radius, int32_t k,
-                              float* irrad) {
+                              float* irrad) try {
   int rc = gather_check(pm, pos, nrm, irrad, n, k);
   if (rc) return rc;
   if (n == 0) return GRT_OK;
@@ -1219,6 +1231,8 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
   } while (0);
   (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out);
   return rc;
+} catch (...) {
+  return grt_fail_exception("grt_photon_gather");
 }
 
 // ---- photon-mapped trace() (scene.go:308-320, commented out in the reference) -----------------
@@ -1244,7 +1258,7 @@ GRT_API uint64_t grt_render_pm_workspace_bytes(const grt_scene* s, const grt_opt
 
 GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int32_t shard,
                                     int32_t n_shards, int32_t samples, float* d_rgb_sum, void* d_workspace,
-                                    uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) {
+                                    uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) try {
   if (!s || !gmap || !cmap || !d_rgb_sum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: bad argument");
   const uint64_t need = grt_render_pm_workspace_bytes(s, o, shard, n_shards, samples);
   if (!d_workspace || workspace_bytes < need)
@@ -1275,6 +1289,8 @@ GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_p
     if (rc) return rc;
   }
   return GRT_OK;
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_pm_dev");
 }
 
 // Host-buffer form on one device: linear RGB sums [H*W*3] (rgb_sum) and / or tone-mapped B,G,R bytes (pixels).
@@ -1314,12 +1330,16 @@ static int render_pm_host(grt_scene* s, const grt_opts* o, const grt_pmap* gmap,
   return rc;
 }
 GRT_API int grt_render_pm(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, uint8_t* pixels, int32_t pitch,
-                          int32_t samples) {
+                          int32_t samples) try {
   if (!pixels || !s || pitch / grt_scene_desc_of(s)->width < 3) return grt_fail(GRT_EINVAL, "grt_render_pm: NULL pixels or pitch too small");
   return render_pm_host(s, o, gmap, cmap, samples, nullptr, pixels, pitch);
+} catch (...) {
+  return grt_fail_exception("grt_render_pm");
 }
 GRT_API int grt_render_accum_pm(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, float* rgb_sum,
-                                int32_t samples) {
+                                int32_t samples) try {
   if (!rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_pm: NULL output");
   return render_pm_host(s, o, gmap, cmap, samples, rgb_sum, nullptr, 0);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_pm");
 }

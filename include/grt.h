@@ -42,6 +42,7 @@ extern "C" {
 #define GRT_EHIP (-2)    /* a HIP runtime call failed; message holds hipGetErrorString */
 #define GRT_ENODEV (-3)  /* no usable gfx950 device */
 #define GRT_ELIMIT (-4)  /* size beyond a documented maximum */
+#define GRT_EHOST (-5)   /* host-side failure inside the library (out of memory, no thread): nothing crosses the C ABI as a C++ exception */
 
 #define GRT_KIND_SPHERE 0
 #define GRT_KIND_AABB 1
