@@ -218,6 +218,30 @@ GRT_DEV int intersect_tab_t(const float4* __restrict__ tp, int n_prims, float bi
   t_out = tbest;
   return best;
 }
+// The same result from a copy of the records sorted by kind (boxes first, each kind in index order,
+// last word = index << 3 | flags as in the hierarchy's leaf records): two loops without a kind
+// branch.  Each loop is the reference's loop restricted to one kind; by the order-free form of the
+// result (grt_bvh.h) the winner of the whole loop is the box loop's winner when that is a box entered
+// within the bias, else the nearer of the two winners, the lower index on equal distance.
+GRT_DEV int intersect_sorted(const float4* __restrict__ ts, int n_boxes, int n_prims, float bias, const Ray32& r, float& t_out) {
+  float tb = 3.402823466e38f, tq = 3.402823466e38f;
+  int ib = -1, iq = -1;
+#pragma unroll 4
+  for (int i = 0; i < n_boxes; ++i) {
+    const float4 pa = ts[2 * i], pb = ts[2 * i + 1];
+    const float ht = aabb_hit32<false>(pa, pb, r, bias, tb);
+    if (ht > 0.0f) ib = (int)((uint32_t)__float_as_int(pb.w) >> 3), tb = ht;
+  }
+#pragma unroll 4
+  for (int i = n_boxes; i < n_prims; ++i) {
+    const float4 pa = ts[2 * i], pb = ts[2 * i + 1];
+    const float ht = sphere_hit32(pa, pb, r, bias, tq);
+    if (ht > 0.0f) iq = (int)((uint32_t)__float_as_int(pb.w) >> 3), tq = ht;
+  }
+  const bool box = (ib >= 0) & ((tb <= bias) | (tb < tq) | ((tb == tq) & (ib < iq)) | (iq < 0));
+  t_out = box ? tb : tq;
+  return box ? ib : iq;
+}
 template <bool CAREFUL>
 GRT_DEV int intersect32_t(const KScene& S, const Ray32& r, float& t_out) {
   float tbest = 3.402823466e38f;
@@ -561,7 +585,8 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                           uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr,
-                          WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0) {
+                          WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, const float4* ts = nullptr,
+                          int n_boxes = 0) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
   if (RELOAD && NP > 0) asm volatile("" ::: "memory");
@@ -572,8 +597,8 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   if (NP < 0)  // NP < 0: bounding-volume hierarchy (grt_bvh.h), per-lane stack in LDS
     id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256)
                                 : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256);
-  else if (NP == 0 && RELOAD)  // mid-size scenes: the same loop over an LDS copy of the objects
-    id = __any(ray_has_zero(r)) ? intersect_tab_t<true>(tp, S.n_prims, S.bias, r, t) : intersect_tab_t<false>(tp, S.n_prims, S.bias, r, t);
+  else if (NP == 0 && RELOAD)  // mid-size scenes: LDS copies of the objects, sorted by kind for the usual rays
+    id = __any(ray_has_zero(r)) ? intersect_tab_t<true>(tp, S.n_prims, S.bias, r, t) : intersect_sorted(ts, n_boxes, S.n_prims, S.bias, r, t);
   else if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
   else if (NP > 0)

@@ -13,7 +13,7 @@
 // The linear-scan kernels (the reference's own algorithm, scene.go:173) read every object
 // for every ray; beyond this many objects a scene goes through the BVH path instead.
 #define GRT_MAX_LINEAR_PRIMS 4096
-#define GRT_BVH_AUTO_PRIMS 160  // GRT_ACCEL_AUTO takes the hierarchy above this (tools/bench_crossover.py: 8.9 vs 9.0 ms at 160 objects)
+#define GRT_BVH_AUTO_PRIMS 208  // GRT_ACCEL_AUTO takes the hierarchy above this (tools/bench_crossover.py: 9.1 vs 9.7 ms at 208, 10.2 vs 9.6 at 224 objects)
 #define GRT_MAX_PRIMS (1 << 26)
 
 int grt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -39,25 +39,57 @@ GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
 // for the unrolled intersect loop.
 #define GRT_FAST_PRIMS 8
 // Mid-size scenes (9 .. GRT_LDS_PRIMS objects and materials, below the hierarchy's crossover): the
-// render kernel keeps the reference's linear loop but reads the records from an LDS copy (every lane
-// the same address: a broadcast) instead of waiting for a scalar load per object.
-#define GRT_LDS_PRIMS 192
+// render kernel keeps the reference's linear loop but reads the records from LDS copies (every lane
+// the same address: a broadcast) instead of waiting for a scalar load per object — one copy in index
+// order for the hit's Surface and material, one sorted by kind so that the loop has no kind branch.
+#define GRT_LDS_PRIMS 224
 
 template <int NP>
 struct SceneTables {
   const float4* tp;
   const float4* tm;
+  const float4* ts = nullptr;  // mid-size scenes: the objects sorted by kind (intersect_sorted)
+  int n_boxes = 0;
 };
 
 // The host pads the staged arrays to GRT_FAST_PRIMS records, so the copies are unconditional.
 template <int NP, bool LDSGEN = false>
 GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
   if (NP == 0 && LDSGEN) {
+    // [0, 2N) objects in index order (Surface and material of the hit), [2N, 4N) materials,
+    // [4N, 6N) objects sorted by kind: a stable partition by the first wave (ballot + mbcnt)
     for (int i = threadIdx.x; i < 2 * S.n_prims; i += blockDim.x) lds[i] = S.prims[i];
     for (int i = threadIdx.x; i < 2 * S.n_mats; i += blockDim.x) lds[2 * GRT_LDS_PRIMS + i] = S.mats[i];
+    float4* sorted = lds + 4 * GRT_LDS_PRIMS;
+    int n_boxes = 0;
+    for (int base = 0; base < S.n_prims; base += 64) {  // every wave counts (uniform), the first one writes
+      const int i = base + (threadIdx.x & 63);
+      n_boxes += __builtin_popcountll(__ballot(i < S.n_prims && (__float_as_int(S.prims[2 * min(i, S.n_prims - 1) + 1].w) & 1)));
+    }
+    if (threadIdx.x < 64) {
+      int bpos = 0, spos = n_boxes;
+      for (int base = 0; base < S.n_prims; base += 64) {
+        const int i = base + threadIdx.x;
+        const bool in = i < S.n_prims;
+        const float4 pa = S.prims[2 * (in ? i : 0)];
+        float4 pb = S.prims[2 * (in ? i : 0) + 1];
+        const int bits = __float_as_int(pb.w);
+        const unsigned long long mb = __ballot(in && (bits & 1)), ms = __ballot(in && !(bits & 1));
+        const int lane_rank_b = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+        const int lane_rank_s = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0));
+        if (in) {
+          const int slot = (bits & 1) ? bpos + lane_rank_b : spos + lane_rank_s;
+          pb.w = __int_as_float((int)((uint32_t)i << 3 | ((uint32_t)bits & 7u)));
+          sorted[2 * slot] = pa, sorted[2 * slot + 1] = pb;
+        }
+        bpos += __builtin_popcountll(mb), spos += __builtin_popcountll(ms);
+      }
+    }
     __syncthreads();
     T.tp = lds;
     T.tm = lds + 2 * GRT_LDS_PRIMS;
+    T.ts = sorted;
+    T.n_boxes = n_boxes;
   } else if (NP > 0) {
     // [0, 2NP) objects, [2NP, 4NP) materials (a scene never has more materials than objects
     // after de-duplication; the host checks n_mats <= NP before choosing this kernel)
@@ -82,7 +114,7 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
 __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
-  __shared__ float4 lds[NP > 0 ? 4 * NP : (NP == 0 && RELOAD ? 4 * GRT_LDS_PRIMS : 1)];
+  __shared__ float4 lds[NP > 0 ? 4 * NP : (NP == 0 && RELOAD ? 6 * GRT_LDS_PRIMS : 1)];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
   __shared__ float qacc[QUEUE ? 4 * 192 : 1];                  // wave-queue mode: [wave][pixel][rgb]
   __shared__ uint32_t qkey[QUEUE ? 4 * 64 : 1];
@@ -136,7 +168,7 @@ __global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float*
     while (__any(alive)) {
       if (alive)
         path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x, nullptr,
-                                           &J.pm, pm_base);
+                                           &J.pm, pm_base, T.ts, T.n_boxes);
     }
     result = L.acc;
   }

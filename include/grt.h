@@ -88,9 +88,9 @@ typedef struct {
   grt_camera cam;
 } grt_scene_desc;
 
-/* How Scene.intersect finds the nearest object.  AUTO: the reference's linear scan up to 160
+/* How Scene.intersect finds the nearest object.  AUTO: the reference's linear scan up to 208
  * objects, a bounding-volume hierarchy above (same result, see csrc/grt_bvh.h; measured crossover
- * at 160 objects, 18x faster at 4096); BVH forces the hierarchy, LINEAR the scan (<= 4096 objects).
+ * near 210 objects, 18x faster at 4096); BVH forces the hierarchy, LINEAR the scan (<= 4096 objects).
  * The shadow loop of the plain-diffuse branch (scene.go:336-344) and the caustic filter of
  * tracePhotons (scene.go:359-363) run through the hierarchy in their order-free forms, so every
  * material, photon emission and photon-mapped rendering work on hierarchy scenes.

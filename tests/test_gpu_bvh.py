@@ -148,13 +148,13 @@ def test_c5_spheres_scene_at_test_size(pkg, ob):
     assert (rel < 0.03).all(), rel
 
 
-def test_auto_takes_the_hierarchy_above_160_objects(pkg, ob):
-    """GRT_ACCEL_AUTO: linear scan up to 160 objects, hierarchy above with or without plain-diffuse objects.
+def test_auto_takes_the_hierarchy_above_208_objects(pkg, ob):
+    """GRT_ACCEL_AUTO: linear scan up to 208 objects, hierarchy above with or without plain-diffuse objects.
     The parity kernel keeps the linear scan + float64 re-test for such scenes (ids exact against the oracle);
     the renderer's frame equals the forced-hierarchy frame bit for bit."""
     C = pkg._capi
     cam = pkg.scenes.cornell_camera(128 / 96)
-    objs = pkg.scenes.random_objects(100, 100, 21, diffuse=False)
+    objs = pkg.scenes.random_objects(120, 120, 21, diffuse=False)
     auto = pkg.tracer.Scene(128, 96, cam, objs)
     forced = pkg.tracer.Scene(128, 96, cam, objs, accel=C.GRT_ACCEL_BVH)
     lin = pkg.tracer.Scene(128, 96, cam, objs, accel=C.GRT_ACCEL_LINEAR)
@@ -164,9 +164,9 @@ def test_auto_takes_the_hierarchy_above_160_objects(pkg, ob):
     ids, t, _, _ = auto.PrimaryHits(0, 1)
     rid, rt, _ = ob.OracleScene(auto.flat).PrimaryHits(0, 1)
     assert (ids == rid).all()
-    small = pkg.tracer.Scene(128, 96, cam, objs[:90])                       # <= 160 objects: linear (LDS copy of the objects)
+    small = pkg.tracer.Scene(128, 96, cam, objs[:90])                       # <= 208 objects: linear (LDS copies of the objects)
     assert (small.RenderAccum(4, seed=5) == pkg.tracer.Scene(128, 96, cam, objs[:90], accel=C.GRT_ACCEL_LINEAR).RenderAccum(4, seed=5)).all()
-    withd = pkg.scenes.random_objects(100, 100, 21, diffuse=True)           # plain diffuse objects: hierarchy all the same
+    withd = pkg.scenes.random_objects(120, 120, 21, diffuse=True)           # plain diffuse objects: hierarchy all the same
     pkg.tracer.Scene(64, 48, cam, withd).RenderAccum(2, seed=1)
     with pytest.raises(C.GrtError, match="linear scan takes at most"):
         pkg.scenes.spheres(5000, 64, 36, accel=C.GRT_ACCEL_LINEAR)
