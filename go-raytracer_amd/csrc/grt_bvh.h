@@ -18,9 +18,11 @@
 // gmin + q * gs per axis), rounded outward by one cell, so a node is two 16-byte words:
 //   nodes[2n+c] = (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, ref)   c = child 0, 1
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = first object slot << 3 | count (<= 7;
-//   2 per leaf walks fastest at C5, deeper scenes take 4 or 7 to fit the traversal stack).
-// The walk is bound by the vector memory path (texture addresser busy 76 % of the kernel at C5
-// with 64-byte FP32 nodes), which moves bytes per lane: halving the node halves that traffic.
+//   1 per leaf walks fastest at C5, deeper scenes take 2, 4 or 7 to fit the traversal stack).
+//   The inner children of a node are neighbours in memory (a 64-byte pair on an even slot, followed
+//   by the pair of the first child's children): a 128-byte line brings the far child with the near one.
+// With 64-byte FP32 nodes the texture addresser was busy 76 % of the kernel at C5: the vector
+// memory path moves bytes per lane, and halving the node halved that traffic.
 // A ray is taken into grid coordinates once (BvhRay): t = q * (gs / D) - (O - gmin) / D.
 // Objects are re-ordered into leaf order (bprims: the 2 x float4 records of KScene::prims with
 // the last word replaced by object index << 3 | transparent << 2 | emissive << 1 | is_box, so a
@@ -29,7 +31,8 @@
 // so a subtree is never culled by a rounding difference between the slab arithmetic here and
 // the object arithmetic of sphere_hit32 / aabb_hit32.
 // Traversal: one ray per lane, nearer child first, the other child on a per-lane stack in LDS
-// (stack[depth][lane]: conflict-free).
+// (stack[depth][lane]: conflict-free).  The same tree serves the reference's two other object loops
+// through bvh_any_hit (the shadow loop of the diffuse branch, the caustic filter of tracePhotons).
 #pragma once
 // (included from the middle of grt_device.h, after the per-object hit functions)
 
