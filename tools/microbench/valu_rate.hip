@@ -1,6 +1,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }  // v_mul_u32_u24
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float s) {
   float t = threadIdx.x * 1e-3f;
@@ -23,6 +24,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s) {
     }
     v2f r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y;
+  } else if (MODE == 3 || MODE == 4 || MODE == 5) {  // integer multiplies (the counter RNG) and a transcendental
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t m = 0x9E3779B1u + (uint32_t)iters;
+    float f0 = t + 1, f1 = t + 2, f2 = t + 3, f3 = t + 4, f4 = t + 5, f5 = t + 6, f6 = t + 7, f7 = t + 8;
+    for (int i = 0; i < iters; ++i) {
+      if (MODE == 3) {
+        a0 *= m; a1 *= m; a2 *= m; a3 *= m; a4 *= m; a5 *= m; a6 *= m; a7 *= m;  // v_mul_lo_u32
+      } else if (MODE == 4) {
+        a0 = mul24(a0, m); a1 = mul24(a1, m); a2 = mul24(a2, m);
+        a3 = mul24(a3, m); a4 = mul24(a4, m); a5 = mul24(a5, m);
+        a6 = mul24(a6, m); a7 = mul24(a7, m);  // v_mul_u32_u24
+      } else {
+        f0 = __builtin_amdgcn_rcpf(f0); f1 = __builtin_amdgcn_rcpf(f1); f2 = __builtin_amdgcn_rcpf(f2); f3 = __builtin_amdgcn_rcpf(f3);
+        f4 = __builtin_amdgcn_rcpf(f4); f5 = __builtin_amdgcn_rcpf(f5); f6 = __builtin_amdgcn_rcpf(f6); f7 = __builtin_amdgcn_rcpf(f7);
+      }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
   } else {  // min/max chain
     float a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3, a4 = t + 4, a5 = t + 5, a6 = t + 6, a7 = t + 7;
     for (int i = 0; i < iters; ++i) {
@@ -54,5 +72,8 @@ int main() {
   run<0>("v_fma_f32 x8", 16);
   run<1>("v_pk_fma_f32 x8", 32);
   run<2>("mul+max / add+min x8", 16);
+  run<3>("v_mul_lo_u32 x8 (flop column: instructions)", 8);
+  run<4>("v_mul_u32_u24 x8 (flop column: instructions)", 8);
+  run<5>("v_rcp_f32 x8 (flop column: instructions)", 8);
   return 0;
 }
