@@ -112,7 +112,10 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
 // for every lane that still has samples left — terminated paths never leave idle lanes
 // behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
-__global__ __launch_bounds__(256) void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
+// The production instance for scenes of <= 8 objects is compiled for 7 waves per SIMD (72 VGPRs, 24 B of
+// scratch): 37.5 ms against 38.1 ms at 6 waves (76 VGPRs) for the C3 frame; 8 waves (64 VGPRs) the same.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NP == GRT_FAST_PRIMS && RELOAD && !PREFETCH && !QUEUE) ? 7 : 4)))
+void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
   __shared__ float4 lds[NP > 0 ? 4 * NP : (NP == 0 && RELOAD ? 6 * GRT_LDS_PRIMS : 1)];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
