@@ -655,10 +655,12 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
     dir = reflect32(r.D, n);
     if (m1.y != 0.0f) {
       f3 fz = sample_hemi32(n, grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 0)), grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 1)));
-      dir = fma3(fz, m1.y, dir);
-      if (!(dot3(dir, n) > 0.0f)) term = true;      // scene.go:291: no ray, black
-      else dir = unit3(dir);                        // keep |D| = 1 (direction unchanged)
+      dir = unit3(fma3(fz, m1.y, dir));             // keep |D| = 1 (direction unchanged)
     }
+    // scene.go:291, tested whatever the roughness: no ray and black when the reflected direction does not
+    // leave the surface — a mirror met from inside (the eye or a secondary origin within a mirror sphere),
+    // or a box whose X->Y->Z epsilon cascade (aabb.go:57-70) names the neighbouring face at an edge
+    if (!(dot3(dir, n) > 0.0f)) term = true;
   }
   if (QUEUE) {
     // only a terminating level carries radiance (emission, NormalMaterial, direct light)
@@ -826,86 +828,85 @@ GRT_DEV float slab_err(float lo, float hi, float o, float inv, float k0, float k
   return 3.0f * u * (fmaxf(fabsf(lo), fabsf(hi)) + fabsf(o)) * fabsf(inv) + 2.0f * u * fmaxf(fabsf(k0), fabsf(k1));
 }
 
-GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_fast) {
+// One object of the loop under first-order error bounds.  (win_lo, win_hi) bracket the exact value of
+// the tMax the object meets (the running best +- its bound; BIG, BIG for tMax = +inf).  Returns
+//   0  the object is certainly not accepted,
+//   1  it is certainly accepted (scene.go:174) with a distance whose exact value lies in [t - e, t + e],
+//   2  FP32 cannot tell.
+GRT_DEV int hit_margin(float4 pa, float4 pb, const Ray32& r, float bias, float Dlen, float Olen, float win_lo, float win_hi,
+                       float& t_out, float& e_out) {
   const float u = 6.0e-8f;
-  const float BIG = 3.402823466e38f;
-  const float Dlen = sqrt32(r.a);
-  const float Olen = sqrt32(dot3(r.O, r.O));
-  bool amb = ray_has_zero(r);
-  float tb = BIG, eb = 0.0f;  // running best t and its error bound
-  int best = -1;
-  for (int i = 0; i < S.n_prims; ++i) {
-    float4 pa = S.prims[2 * i], pb = S.prims[2 * i + 1];
-    if (__float_as_int(pb.w) & 1) {
-      float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
-      float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
-      float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
-      float ex = slab_err(pa.x, pb.x, r.O.x, r.invD.x, x0, x1);
-      float ey = slab_err(pa.y, pb.y, r.O.y, r.invD.y, y0, y1);
-      float ez = slab_err(pa.z, pb.z, r.O.z, r.invD.z, z0, z1);
-      float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
-      float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
-      float t0 = fmaxf(fmaxf(nx, ny), nz);
-      float t0lo = fmaxf(fmaxf(nx - ex, ny - ey), nz - ez), t0hi = fmaxf(fmaxf(nx + ex, ny + ey), nz + ez);
-      float t1lo = fminf(fminf(fx - ex, fy - ey), fz - ez), t1hi = fminf(fminf(fx + ex, fy + ey), fz + ez);
-      float lo_lo = fmaxf(S.bias, t0lo), lo_hi = fmaxf(S.bias, t0hi);
-      float hi_lo = fminf(tb - eb, t1lo), hi_hi = fminf(tb + eb, t1hi);
-      bool def_hit = hi_lo > lo_hi, def_miss = hi_hi < lo_lo;
-      if (!def_hit && !def_miss) amb = true;
-      if (def_hit) {
-        if (t0lo > 0.0f) {
-          best = i;
-          tb = t0;
-          eb = fmaxf(t0hi - t0, t0 - t0lo);
-        } else if (!(t0hi < 0.0f)) {
-          amb = true;
-        }
+  if (__float_as_int(pb.w) & 1) {
+    float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
+    float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
+    float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);
+    float ex = slab_err(pa.x, pb.x, r.O.x, r.invD.x, x0, x1);
+    float ey = slab_err(pa.y, pb.y, r.O.y, r.invD.y, y0, y1);
+    float ez = slab_err(pa.z, pb.z, r.O.z, r.invD.z, z0, z1);
+    float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
+    float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
+    float t0 = fmaxf(fmaxf(nx, ny), nz);
+    float t0lo = fmaxf(fmaxf(nx - ex, ny - ey), nz - ez), t0hi = fmaxf(fmaxf(nx + ex, ny + ey), nz + ez);
+    float t1lo = fminf(fminf(fx - ex, fy - ey), fz - ez), t1hi = fminf(fminf(fx + ex, fy + ey), fz + ez);
+    float lo_lo = fmaxf(bias, t0lo), lo_hi = fmaxf(bias, t0hi);
+    float hi_lo = fminf(win_lo, t1lo), hi_hi = fminf(win_hi, t1hi);
+    bool def_hit = hi_lo > lo_hi, def_miss = hi_hi < lo_lo;
+    if (!def_hit && !def_miss) return 2;
+    if (def_hit) {
+      if (t0lo > 0.0f) {
+        t_out = t0;
+        e_out = fmaxf(t0hi - t0, t0 - t0lo);
+        return 1;
       }
-    } else {
-      f3 C = mk3(pa.x, pa.y, pa.z);
-      f3 oc = r.O - C;
-      float ocl = sqrt32(dot3(oc, oc));
-      float eoc = 1.5f * u * (sqrt32(dot3(C, C)) + Olen + ocl);  // |delta oc|
-      float halfB = dot3(oc, r.D);
-      float k = halfB * r.inva;
-      f3 l = fma3(r.D, -k, oc);
-      float ll = dot3(l, l), ln = sqrt32(ll);
-      float dp = pb.x - ll;
-      float e_hb = Dlen * eoc + 4.0f * u * ocl * Dlen;
-      float ek = e_hb * r.inva + 8.0f * u * fabsf(k);
-      float el = eoc + ek * Dlen + 2.0f * u * (fabsf(k) * Dlen + ln);
-      float edp = 2.0f * ln * el + el * el + 3.0f * u * (ll + pb.x);
-      if (dp + edp < 0.0f) continue;  // definitely no real root
-      if (dp - edp <= 0.0f) {
-        amb = true;
-        continue;
-      }
-      float s2 = dp * r.inva, es2 = edp * r.inva + 8.0f * u * s2;
-      float sq = sqrt32(s2);
-      float es = es2 * rcp32(sq + sqrt32(fmaxf(s2 - es2, 0.0f))) + 2.0f * u * sq;
-      float et = ek + es + 2.0f * u * (fabsf(k) + sq);
-      float t1 = -k - sq, t2 = -k + sq;
-      float hi_lo = tb - eb, hi_hi = tb + eb;
-      float t = -1.0f;
-      bool in1 = (t1 - et > S.bias) && (t1 + et < hi_lo), out1 = (t1 + et <= S.bias) || (t1 - et >= hi_hi);
-      if (in1) {
-        t = t1;
-      } else if (!out1) {
-        amb = true;
-      } else {
-        bool in2 = (t2 - et > S.bias) && (t2 + et < hi_lo), out2 = (t2 + et <= S.bias) || (t2 - et >= hi_hi);
-        if (in2) t = t2;
-        else if (!out2) amb = true;
-      }
-      if (t > 0.0f) {
-        best = i;
-        tb = t;
-        eb = et;
-      }
+      if (!(t0hi < 0.0f)) return 2;
     }
+    return 0;
   }
-  if (best != id_fast) amb = true;  // cannot happen for unambiguous lanes; belt and braces
-  if (best < 0 || amb) return amb;
+  f3 C = mk3(pa.x, pa.y, pa.z);
+  f3 oc = r.O - C;
+  float ocl = sqrt32(dot3(oc, oc));
+  float eoc = 1.5f * u * (sqrt32(dot3(C, C)) + Olen + ocl);  // |delta oc|
+  float halfB = dot3(oc, r.D);
+  float k = halfB * r.inva;
+  f3 l = fma3(r.D, -k, oc);
+  float ll = dot3(l, l), ln = sqrt32(ll);
+  float dp = pb.x - ll;
+  float e_hb = Dlen * eoc + 4.0f * u * ocl * Dlen;
+  float ek = e_hb * r.inva + 8.0f * u * fabsf(k);
+  float el = eoc + ek * Dlen + 2.0f * u * (fabsf(k) * Dlen + ln);
+  float edp = 2.0f * ln * el + el * el + 3.0f * u * (ll + pb.x);
+  if (dp + edp < 0.0f) return 0;  // definitely no real root
+  if (dp - edp <= 0.0f) return 2;
+  float s2 = dp * r.inva, es2 = edp * r.inva + 8.0f * u * s2;
+  float sq = sqrt32(s2);
+  float es = es2 * rcp32(sq + sqrt32(fmaxf(s2 - es2, 0.0f))) + 2.0f * u * sq;
+  float et = ek + es + 2.0f * u * (fabsf(k) + sq);
+  float t1 = -k - sq, t2 = -k + sq;
+  float t = -1.0f;
+  bool in1 = (t1 - et > bias) && (t1 + et < win_lo), out1 = (t1 + et <= bias) || (t1 - et >= win_hi);
+  if (in1) {
+    t = t1;
+  } else if (!out1) {
+    return 2;
+  } else {
+    bool in2 = (t2 - et > bias) && (t2 + et < win_lo), out2 = (t2 + et <= bias) || (t2 - et >= win_hi);
+    if (in2) t = t2;
+    else if (!out2) return 2;
+  }
+  if (t > 0.0f) {
+    t_out = t;
+    e_out = et;
+    return 1;
+  }
+  return 0;
+}
+
+// The winner is certain (object `best` at tb +- eb): can the FP32 t and Surface() normal miss the parity
+// tolerance (1e-5 relative), or the face choice of AABB.Surface's cascade (aabb.go:57-70) come out
+// differently in exact arithmetic?
+GRT_DEV bool hit_accuracy_doubtful(const KScene& S, const Ray32& r, int best, float tb, float eb, float t_fast) {
+  const float u = 6.0e-8f;
+  const float Dlen = sqrt32(r.a);
   if (!(fabsf(tb - t_fast) <= eb)) return true;
   if (eb > 8e-6f * fabsf(tb)) return true;  // t must hold 1e-5 relative
   float4 pa = S.prims[2 * best], pb = S.prims[2 * best + 1];
@@ -945,4 +946,22 @@ GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_f
     if (en > 8e-6f) return true;
   }
   return false;
+}
+
+GRT_DEV bool ambiguous32(const KScene& S, const Ray32& r, int id_fast, float t_fast) {
+  const float BIG = 3.402823466e38f;
+  const float Dlen = sqrt32(r.a);
+  const float Olen = sqrt32(dot3(r.O, r.O));
+  bool amb = ray_has_zero(r);
+  float tb = BIG, eb = 0.0f;  // running best t and its error bound
+  int best = -1;
+  for (int i = 0; i < S.n_prims; ++i) {
+    float t, e;
+    const int st = hit_margin(S.prims[2 * i], S.prims[2 * i + 1], r, S.bias, Dlen, Olen, tb - eb, tb + eb, t, e);
+    if (st == 2) amb = true;
+    if (st == 1) best = i, tb = t, eb = e;
+  }
+  if (best != id_fast) amb = true;  // cannot happen for unambiguous lanes; belt and braces
+  if (best < 0 || amb) return amb;
+  return hit_accuracy_doubtful(S, r, best, tb, eb, t_fast);
 }

@@ -9,6 +9,7 @@
 // k_primary_sweep FP32 intersection roofline loop (C2 roofline variant)
 #pragma once
 #include "grt_device.h"
+#include "grt_parity.h"
 
 // Work decomposition of one shard of a frame.  A wave owns one 8x8 pixel tile for one chunk
 // of the sample range; tile rows coincide with the GRT_BAND_ROWS-row bands that are dealt
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __re
 
 // Config C2, parity variant.  FP32 intersect32/surface32 (the functions the renderer uses);
 // lanes whose decision margin is small (ambiguous32) are re-tested in FP64 with the
-// reference's operation order, which makes hit/miss and the object id bit-exact.
+// reference's operation order, which makes hit/miss and the object id bit-exact.  Hierarchy
+// scenes take the same three steps through the walks of grt_parity.h.
 __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, int jitter_mode, int* __restrict__ id_out,
                                                       float* __restrict__ t_out, float* __restrict__ n_out,
                                                       unsigned long long* __restrict__ fallback_count,
@@ -420,17 +422,60 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   float t;
   int id;
   __shared__ int bvh_stack[GRT_BVH_STACK * 256];
-  if (S.bvh_nodes) {  // large scenes: FP32 through the hierarchy; the FP64 re-test (a linear scan) is not run
-    id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256)
-                                : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256);
-    force_mode = 1;
-  } else {
-    id = intersect32(S, r, t);
+  bool amb;
+  if (S.bvh_nodes) {  // hierarchy scenes (grt_parity.h)
+    int* stack = bvh_stack + threadIdx.x;
+    const bool careful = __any(ray_has_zero(r));
+    float eb = 0.0f;
+    amb = false;
+    if (force_mode == 1)  // the renderer's own walk
+      id = careful ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, stack, 256)
+                   : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, stack, 256);
+    else if (force_mode == 2)
+      id = -1, amb = true;
+    else
+      id = careful ? intersect_bvh_margin<true>(S, r, t, eb, amb, stack, 256) : intersect_bvh_margin<false>(S, r, t, eb, amb, stack, 256);
+    f3 p, nn32 = mk3(0.0f, 0.0f, 0.0f);
+    if (!amb && id >= 0) surface32(S, id, r, t, p, nn32);
+    // a certified winner whose FP32 t or normal may miss 1e-5: its own Hit and Surface in float64, no walk
+    bool refine = force_mode == 0 && !amb && id >= 0 && hit_accuracy_doubtful(S, r, id, t, eb, t);
+    double t64 = 0.0;
+    if (refine) {
+      t64 = prim_hit64(S64.prims + 8 * (size_t)id, O64, D64, S64.bias, 1.7976931348623157e308);
+      if (!(t64 > S64.bias)) amb = true, refine = false;  // cannot happen for a certified winner; belt and braces
+    }
+    if (__any(amb)) {
+      double tw;
+      const int id64 = careful ? intersect_bvh64<true>(S, S64, r, O64, D64, amb, tw, stack, 256)
+                               : intersect_bvh64<false>(S, S64, r, O64, D64, amb, tw, stack, 256);
+      if (amb) id = id64, t64 = tw;
+    }
+    f3 nn = nn32;
+    if (id < 0) t = 0.0f, nn = mk3(0.0f, 0.0f, 0.0f);
+    if ((amb | refine) && id >= 0) {
+      const d3 n64 = surface64(S64.prims + 8 * (size_t)id, O64, D64, t64);
+      nn = mk3((float)n64.x, (float)n64.y, (float)n64.z);
+      t = (float)t64;
+    }
+    amb |= refine;  // counted as re-tested in float64
+    if (valid) {
+      id_out[i] = id;
+      t_out[i] = t;
+      n_out[i * 3 + 0] = nn.x;
+      n_out[i * 3 + 1] = nn.y;
+      n_out[i * 3 + 2] = nn.z;
+    }
+    if (fallback_count) {
+      unsigned long long m = __ballot(amb && valid);
+      if ((threadIdx.x & 63) == 0 && m) atomicAdd(fallback_count, (unsigned long long)__popcll(m));
+    }
+    return;
   }
+  id = intersect32(S, r, t);
   f3 p, nn = mk3(0.0f, 0.0f, 0.0f);
   if (id >= 0) surface32(S, id, r, t, p, nn);
   else t = 0.0f;
-  bool amb = force_mode == 2 || (force_mode == 0 && ambiguous32(S, r, id, t));
+  amb = force_mode == 2 || (force_mode == 0 && ambiguous32(S, r, id, t));
   if (amb) {
     double t64;
     id = intersect64(S64, S.n_prims, O64, D64, t64);

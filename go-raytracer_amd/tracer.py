@@ -294,8 +294,8 @@ class Scene:
         return rgb, nr
 
     def PrimaryHits(self, jitter_mode=_capi.GRT_JITTER_CENTER, seed=1, mode=0):
-        """mode: 0 = FP32 with FP64 re-test of ambiguous lanes, 1 = FP32 only, 2 = FP64 only
-        (scenes that use the hierarchy always run FP32 only)."""
+        """mode: 0 = FP32 with FP64 re-test of ambiguous lanes, 1 = FP32 only (the renderer's own
+        intersect), 2 = FP64 only; on linear-scan and hierarchy scenes alike."""
         n = self.W * self.H
         ids = np.empty(n, np.int32)
         t = np.empty(n, np.float32)

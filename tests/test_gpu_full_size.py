@@ -232,10 +232,11 @@ def test_c5_million_spheres_hits_equal_a_brute_force_scan(pkg):
     ref_i, ref_t = best_i.cpu().numpy(), best_t.cpu().numpy()
     got_i, got_t = ids[ys, xs], t[ys, xs]
     assert (ref_i >= 2).mean() > 0.5                                         # most of these rays hit a sphere
-    same = got_i == ref_i
-    assert same.mean() > 0.998, same.mean()                                  # FP32 silhouettes (no float64 re-test on this path)
-    hit = same & (ref_i >= 0)
-    assert (np.abs(got_t[hit] - ref_t[hit]) / ref_t[hit]).max() < 1e-4
+    assert (got_i == ref_i).all(), (got_i != ref_i).sum()                   # float64 re-test of uncertain lanes (grt_parity.h)
+    hit = ref_i >= 0
+    assert (np.abs(got_t[hit] - ref_t[hit]) / ref_t[hit]).max() < 1e-5
+    fp32_i = scene.PrimaryHits(0, 1, mode=1)[0][ys, xs]                      # the renderer's FP32 walk alone
+    assert (fp32_i == ref_i).mean() > 0.998
 
 
 def test_c4_full_frame_photon_mapped_render_with_dark_photons_is_the_plain_render(pkg):

@@ -35,9 +35,42 @@ def test_per_sample_radiance(pkg, ob, variant):
     same_len = (g_nr == o_nr).mean()
     close = np.isclose(g_rgb, o_rgb, rtol=2e-3, atol=1e-5).all(-1).mean()
     print(f"{variant}: same path length {same_len:.5f}, radiance within 2e-3: {close:.5f}")
-    assert same_len > 0.995 and close > 0.995
+    assert same_len > 0.9995 and close > 0.9995           # measured: 1.00000 / 1.00000 on all three scenes
     # the sample mean over all tested paths is unbiased either way
     assert np.allclose(g_rgb.mean((0, 1)), o_rgb.mean((0, 1)), rtol=0.02, atol=1e-4)
+
+
+def test_mirror_met_from_inside_returns_black(pkg, ob):
+    """scene.go:291 tests reflected.Dot(n) > 0 whatever the roughness.  With roughness 0 the reflected
+    direction has reflected.n = -(incident.n), so a mirror met with incident.n >= 0 ends the path in black:
+    (a) the eye inside a mirror sphere; (b) a mirror box whose front face is hit within 1e-4 of its X edge,
+    where AABB.Surface's X->Y->Z cascade (aabb.go:57-70) names the neighbouring -X face.  Radiance and the
+    number of intersect() calls of every sample against the float64 oracle, on the unrolled, the
+    rolled-loop and the hierarchy kernels."""
+    T, C = pkg.tracer, pkg._capi
+    mirror = T.MetalicMaterial(T.NewColor(1, 1, 1), 1, 0)
+    light = T.LightMaterial(T.NewColor(0.2, 0.2, 0.2), 10)
+    W = H = 48
+    xy = np.stack(np.meshgrid(np.arange(W), np.arange(H)), -1).reshape(-1, 2)
+    # (a) eye inside the mirror sphere, a small light inside it as well
+    inside = [T.NewSphere((278, 273, -790), 60, mirror), T.NewSphere((285, 280, -770), 4, light)]
+    # (b) the image spans 8e-4 units across the box's x = 2 edge on its front face z = 2; the eye stands at
+    # x = 3.5, so the rays travel towards -X; what the mirror reflects ends on the light behind the eye
+    edge = [T.NewAABB((2, 2, 2), (4, 4, 4), mirror), T.NewAABB((-50, -50, -21), (50, 50, -20), light)]
+    cam_b = T.NewCamera((3.5, 3.0, -8.0), (2.0001, 3.0, 2.0), (0, 1, 0), 2 * np.degrees(np.arctan(4e-4 / 10.1)), 1.0)
+    for objs, cam in ((inside, pkg.scenes.cornell_camera(1.0)), (edge, cam_b)):
+        for accel in (C.GRT_ACCEL_AUTO, C.GRT_ACCEL_BVH):
+            scene = T.Scene(W, H, cam, objs, accel=accel)
+            g_rgb, g_nr = scene.TraceSamples(xy, 4, seed=3)
+            o_rgb, o_nr = ob.OracleScene(scene.flat).TraceSamples(xy, 4, seed=3)
+            same = (g_nr == o_nr) & np.isclose(g_rgb, o_rgb, rtol=1e-4, atol=1e-6).all(-1)
+            assert same.mean() > 0.999, same.mean()
+            assert (o_nr == 1).mean() > 0.1 and (o_rgb.sum(-1) > 0).mean() > 0.02   # both outcomes occur
+            # a path that met the mirror from inside made ONE intersect() call and is black
+            black = (o_nr == 1) & (o_rgb.sum(-1) == 0)
+            assert (g_rgb[black].sum(-1) == 0).mean() > 0.999
+            a = scene.RenderAccum(4, seed=3).reshape(-1, 3)                     # the render kernels share path_shade
+            assert np.isclose(a, g_rgb.sum(1), rtol=1e-5, atol=1e-6).all(-1).mean() > 0.999
 
 
 @pytest.mark.parametrize("variant,spp", [("cornell8", 64), ("cornell8d", 16)])
