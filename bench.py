@@ -7,9 +7,10 @@ tile-sharded over the ranks in interleaved 8-row bands.  One step = one whole fr
 rank path-traces its bands (grt_render_accum_dev) and rank 0 gathers them over RCCL.
 Total work is fixed as N grows ("strong" scaling).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps 10 --warmup 2        (N > 1: starts its N ranks itself, as children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --dry-run                    (CPU, gloo: launcher + sharding bookkeeping only)
 
 Prints ONE JSON line on rank 0.  `value` = paths (camera samples) per second over the whole
 job in Msamples/s, inputs (the scene) resident in HBM before the timed region.
@@ -31,12 +32,46 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32 (MI355X_MICROARCH.md, chip-le
 MEASURED_VALU_ISSUE_PER_S = 1.00e12  # v_fma_f32 wave-instructions per second, tools/microbench/valu_rate.hip on MI355X
 
 
+def host_cpu_share():
+    """(CPUs this process may use, how that was found, CPUs of the whole machine, model string).  Go's
+    runtime.NumCPU() (scene.go:106) counts the CPUs in the process's affinity mask; on a shared GPU host the
+    operator's share is narrower than the mask and is stated through OMP_NUM_THREADS / the cgroup quota."""
+    total = os.cpu_count() or 1
+    share, how = total, "os.cpu_count()"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < share:
+            share, how = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < share:
+            share, how = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if 0 < omp < share:
+        share, how = omp, "OMP_NUM_THREADS (the operator's CPU share of this box)"
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return share, how, total, model
+
+
 def cpu_baseline(pkg, width, height):
-    """The float64 C restatement of the reference (oracle/, kind "port") on the host cores,
-    same scene and resolution at a bounded sample count."""
+    """The float64 C restatement of the reference (oracle/, kind "port") on the host cores: the bench's own
+    scene and resolution at a bounded sample count, and BASELINE.md's C1 (640x640, 16 spp, aspect 1).
+    Workers = NumCPU() + 1 as Scene.Render starts them (scene.go:106), NumCPU = this process's CPU share."""
     from oracle import binding as ob
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    share, how, total, model = host_cpu_share()
+    threads = share + 1
     spp = 32
     s = ob.OracleScene(pkg.scenes.cornell_flat(width, height))
     s.RenderAccum(1, seed=1, row_begin=0, row_end=min(64, height), nthreads=threads)  # warm up threads / caches
@@ -44,10 +79,42 @@ def cpu_baseline(pkg, width, height):
     s.RenderAccum(spp, seed=1, nthreads=threads)
     dt = time.perf_counter() - t0
     n = width * height * spp
+    rays = s.last_ray_count()
+    c1 = ob.OracleScene(pkg.scenes.cornell_flat(640, 640))
+    t1 = time.perf_counter()
+    c1.RenderAccum(16, seed=1, nthreads=threads)
+    dt1 = time.perf_counter() - t1
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"cornell8 {width}x{height} at {spp} spp (all rows), float64 C restatement of the Go "
-                      f"reference, {threads} worker threads, {dt:.2f} s wall",
-            "rays_per_s": s.last_ray_count() / dt}
+                      f"reference, {threads} worker threads (NumCPU()+1, scene.go:106), {dt:.2f} s wall",
+            "rays_per_s": rays / dt,
+            "host": {"cpu_model": model, "os_cpu_count": total, "cpu_share": share, "cpu_share_from": how},
+            "c1": {"value": 640 * 640 * 16 / dt1 / 1e6, "unit": "Msamples/s", "seconds": dt1, "rays_per_s": c1.last_ray_count() / dt1,
+                   "sample": "BASELINE.md C1: cornell8 640x640 aspect 1, 16 spp, whole frame"}}
+
+
+def dry_run(args, rank, world):
+    """Launcher + sharding bookkeeping on CPU (gloo): every rank reports the rows of its interleaved bands;
+    together they must cover the frame exactly once.  No pixel is computed (there is no CPU path)."""
+    import torch
+    import torch.distributed as dist
+
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    cover = torch.zeros(args.height, dtype=torch.int64)
+    cover[shard.band_rows(args.height, rank, world)] += 1
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(cover)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(seen.item()),
+                          "rows_covered_once": bool((cover == 1).all()), "launched_by": "self" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -60,7 +127,15 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--chunk-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks meet over gloo and check that their bands cover the frame (launcher test)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` as typed: start the N ranks as children (before anything touches the GPU)
+    launch = importlib.import_module("go-raytracer_amd.launch")
+    rc = launch.self_launch(__file__, sys.argv[1:], args.gpus)
+    if rc is not None:
+        raise SystemExit(rc)
 
     import torch
     import torch.distributed as dist
@@ -69,7 +144,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)

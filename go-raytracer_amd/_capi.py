@@ -75,6 +75,7 @@ PROTOTYPES = {
     "grt_primary_sweep_dev": (C.c_int, [_vp, P(Opts), C.c_int32, _vp, _vp]),
     "grt_photon_build": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, P(_vp)]),
     "grt_photon_count": (C.c_int32, [_vp]),
+    "grt_photon_device": (C.c_int32, [_vp]),
     "grt_photon_read": (C.c_int, [_vp, _vp, _vp, _vp]),
     "grt_photon_load": (C.c_int, [P(Opts), _vp, _vp, _vp, C.c_int32, P(_vp)]),
     "grt_photon_emit_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),

@@ -835,9 +835,18 @@ static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_
   if (G == 1) {
     render_shard_host(s, &opts, opts.first_device, 0, 1, samples, rgb_sum, pixels, pitch, &res[0]);
   } else {
+    // a thread that cannot start (std::system_error) must not leave joinable threads behind: their destructors
+    // would call std::terminate, which no function-try-block catches
     std::vector<std::thread> th;
-    for (int g = 0; g < G; ++g)
-      th.emplace_back(render_shard_host, s, &opts, opts.first_device + g, g, G, samples, rgb_sum, pixels, pitch, &res[g]);
+    th.reserve(G);
+    try {
+      for (int g = 0; g < G; ++g)
+        th.emplace_back(render_shard_host, s, &opts, opts.first_device + g, g, G, samples, rgb_sum, pixels, pitch, &res[g]);
+    } catch (...) {
+      for (auto& t : th) t.join();
+      (void)hipSetDevice(cur);
+      throw;
+    }
     for (auto& t : th) t.join();
   }
   (void)hipSetDevice(cur);
@@ -886,6 +895,7 @@ GRT_API int grt_trace_samples(grt_scene* s, const grt_opts* o, const int32_t* pi
       return grt_fail(GRT_EINVAL, "grt_trace_samples: pixel %d outside the image", i);
   const size_t n = (size_t)n_pixels * samples;
   if (n == 0) return GRT_OK;
+  DeviceGuard guard;
   int rc = use_device(o);
   if (rc) return rc;
   KScene ks;
@@ -936,6 +946,7 @@ GRT_API int grt_primary_hits(grt_scene* s, const grt_opts* o, int32_t jitter_mod
   if (!s || !id || !t || !normal_xyz) return grt_fail(GRT_EINVAL, "grt_primary_hits: NULL argument");
   if (jitter_mode != GRT_JITTER_CENTER && jitter_mode != GRT_JITTER_RNG)
     return grt_fail(GRT_EINVAL, "grt_primary_hits: unknown jitter mode %d", jitter_mode);
+  DeviceGuard guard;
   int rc = use_device(o);
   if (rc) return rc;
   KScene ks;

@@ -25,6 +25,21 @@ int grt_fail_exception(const char* entry_point);  // inside a catch (...): the c
     if (e_ != hipSuccess) return grt_fail(GRT_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// Host-buffer entry points select a device (grt_opts.first_device, or the one a photon map lives on);
+// the caller's current device is what it was when they return.  "_dev" entry points never switch: they
+// work on the CURRENT device.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct DeviceScene {
   float4* prims = nullptr;
   float4* mats = nullptr;

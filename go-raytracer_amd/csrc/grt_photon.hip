@@ -434,6 +434,7 @@ static int pick_device(const grt_opts* o, int* dev) {
 GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photons, int32_t caustics, grt_pmap** out) try {
   if (!s || !out || max_photons <= 0) return grt_fail(GRT_EINVAL, "grt_photon_build: bad argument");
   if (s->lights.empty()) return grt_fail(GRT_EINVAL, "grt_photon_build: the scene has no light (Emittance > 0)");
+  DeviceGuard guard;
   int dev;
   int rc = pick_device(o, &dev);
   if (rc) return rc;
@@ -535,6 +536,7 @@ GRT_API int grt_photon_build(grt_scene* s, const grt_opts* o, int32_t max_photon
 GRT_API int grt_photon_load(const grt_opts* o, const float* pos, const float* power, const uint8_t* theta_phi, int32_t n,
                             grt_pmap** out) try {
   if (!pos || !power || !theta_phi || n < 0 || !out) return grt_fail(GRT_EINVAL, "grt_photon_load: bad argument");
+  DeviceGuard guard;
   int dev;
   int rc = pick_device(o, &dev);
   if (rc) return rc;
@@ -647,9 +649,13 @@ GRT_API int grt_photon_emit_dev(grt_scene* s, const grt_opts* o, int32_t caustic
 GRT_API int grt_photon_load_dev(const grt_opts* o, const float* d_pos4, const float* d_pow4, int32_t n, float power_scale,
                                 uint64_t emitted, grt_pmap** out) try {
   if (n < 0 || !out || (n > 0 && (!d_pos4 || !d_pow4))) return grt_fail(GRT_EINVAL, "grt_photon_load_dev: bad argument");
-  int dev;
-  int rc = pick_device(o, &dev);
-  if (rc) return rc;
+  // A "_dev" entry point: the arrays live on the CURRENT device and the map is built there.  opts->first_device
+  // is not consulted and the current device is not switched (one process per GPU: rank r's current device is
+  // GPU r, and a map built on GPU 0 from GPU r's pointers would fault).
+  (void)o;
+  int dev = 0;
+  GRT_HIP(hipGetDevice(&dev));
+  int rc = GRT_OK;
   grt_pmap* pm = new grt_pmap;
   pm->max = n;
   pm->device = dev;
@@ -674,10 +680,12 @@ GRT_API int grt_photon_load_dev(const grt_opts* o, const float* d_pos4, const fl
 }
 
 GRT_API int32_t grt_photon_count(const grt_pmap* pm) { return pm ? pm->n : 0; }
+GRT_API int32_t grt_photon_device(const grt_pmap* pm) { return pm ? pm->device : -1; }
 GRT_API uint64_t grt_photon_emitted(const grt_pmap* pm) { return pm ? pm->emitted : 0; }
 
 GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_t* theta_phi) try {
   if (!pm) return grt_fail(GRT_EINVAL, "grt_photon_read: NULL map");
+  DeviceGuard guard;
   GRT_HIP(hipSetDevice(pm->device));
   const size_t n = (size_t)pm->n;
   std::vector<float> p3(3 * (n + 1));
@@ -701,6 +709,7 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
 
 GRT_API void grt_photon_free(grt_pmap* pm) {
   if (!pm) return;
+  DeviceGuard guard;
   if (hipSetDevice(pm->device) == hipSuccess) {
     (void)hipFree(pm->d_pos3);
     (void)hipFree(pm->d_pwb);
@@ -1215,6 +1224,7 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
   int rc = gather_check(pm, pos, nrm, irrad, n, k);
   if (rc) return rc;
   if (n == 0) return GRT_OK;
+  DeviceGuard guard;
   GRT_HIP(hipSetDevice(pm->device));
   float *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr;
   const size_t b3 = (size_t)n * 3 * sizeof(float);
@@ -1298,8 +1308,12 @@ static int render_pm_host(grt_scene* s, const grt_opts* o, const grt_pmap* gmap,
                           uint8_t* pixels, int pitch) {
   if (!s || !gmap || !cmap || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_pm: bad argument");
   if (o && o->n_devices > 1) return grt_fail(GRT_ELIMIT, "grt_render_pm: one device per call (shard with grt_render_accum_pm_dev)");
+  DeviceGuard guard;
   int dev;
   int rc = pick_device(o, &dev);
+  if (!rc && (gmap->device != dev || cmap->device != dev))
+    rc = grt_fail(GRT_EINVAL, "grt_render_pm: the photon maps live on devices %d and %d, the render was asked for device %d", gmap->device,
+                  cmap->device, dev);
   if (rc) return rc;
   const int W = grt_scene_desc_of(s)->width, H = grt_scene_desc_of(s)->height;
   const size_t nfl = (size_t)W * H * 3;

@@ -23,6 +23,8 @@ import (
 	"unsafe"
 )
 
+const maxPrims = 1 << 26 // GRT_MAX_PRIMS of the library
+
 func vec3(dst *[3]C.double, e [3]float64) {
 	for k := 0; k < 3; k++ {
 		dst[k] = C.double(e[k])
@@ -46,10 +48,20 @@ func (scene Scene) Render(pixels []byte, pitch int, samples int) {
 	// is retained by C (cgo pointer rule).  One material record per object: no de-duplication
 	// needed for correctness.
 	n := len(scene.Objects)
-	prims := (*[1 << 20]C.grt_prim)(C.calloc(C.size_t(n+1), C.size_t(unsafe.Sizeof(C.grt_prim{}))))
-	mats := (*[1 << 20]C.grt_material)(C.calloc(C.size_t(n+1), C.size_t(unsafe.Sizeof(C.grt_material{}))))
-	defer C.free(unsafe.Pointer(prims))
-	defer C.free(unsafe.Pointer(mats))
+	if n > maxPrims { // the library's own limit (GRT_MAX_PRIMS): fail here with the count, not with an index panic
+		log.Fatalf("render_hip: %d objects; the library takes at most %d", n, maxPrims)
+	}
+	primMem := C.calloc(C.size_t(n+1), C.size_t(unsafe.Sizeof(C.grt_prim{})))
+	matMem := C.calloc(C.size_t(n+1), C.size_t(unsafe.Sizeof(C.grt_material{})))
+	if primMem == nil || matMem == nil {
+		log.Fatal("render_hip: out of memory for the object records")
+	}
+	defer C.free(primMem)
+	defer C.free(matMem)
+	// Slices over the C arrays with their true length (go.mod says go 1.15: unsafe.Slice is 1.17, so the
+	// array type only names an upper bound no scene reaches and the slice expression sets len and cap to n+1)
+	prims := (*[maxPrims + 1]C.grt_prim)(primMem)[: n+1 : n+1]
+	mats := (*[maxPrims + 1]C.grt_material)(matMem)[: n+1 : n+1]
 	for i, o := range scene.Objects {
 		switch h := o.(type) {
 		case Sphere:

@@ -359,6 +359,10 @@ class PhotonMap:
     def emitted(self):
         return int(self._lib.grt_photon_emitted(self.handle))
 
+    def device(self):
+        """HIP ordinal of the device the map lives on."""
+        return int(self._lib.grt_photon_device(self.handle))
+
     def read(self):
         n = self.count()
         pos, power, tp = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty((n, 2), np.uint8)

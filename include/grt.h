@@ -20,7 +20,9 @@
  *     numpy arrays can be passed directly (cgo pointer rule);
  *   - host buffers are caller-owned and never retained after the call returns;
  *   - "_dev" entry points take DEVICE pointers and a HIP stream (void* = hipStream_t,
- *     NULL = the null stream) and enqueue work without synchronising;
+ *     NULL = the null stream), work on the CURRENT device and enqueue without synchronising;
+ *     host-buffer entry points select opts->first_device (or the device a photon map lives
+ *     on) and leave the caller's current device as they found it;
  *   - object id == index into the prims array == index into Scene.Objects
  *     (cmd/raytracer/main.go:40-49); -1 means miss.
  *
@@ -202,6 +204,8 @@ int grt_primary_sweep_dev(grt_scene* scene, const grt_opts* opts, int32_t sample
 int grt_photon_build(grt_scene* scene, const grt_opts* opts, int32_t max_photons, int32_t caustics,
                      grt_pmap** out);
 int32_t grt_photon_count(const grt_pmap* pmap);
+/* HIP ordinal of the device the map's photons and tree live on. */
+int32_t grt_photon_device(const grt_pmap* pmap);
 /* Photons emitted to fill the map (the reference's loop count, scene.go:152/157). */
 uint64_t grt_photon_emitted(const grt_pmap* pmap);
 /* Copies the stored photons, in storage (= emission) order, to host arrays: pos[n*3],
@@ -223,6 +227,8 @@ int grt_photon_emit_dev(grt_scene* scene, const grt_opts* opts, int32_t caustics
                         uint64_t first, int32_t count, float* d_pos4, float* d_pow4,
                         int32_t* d_stored, void* d_workspace, uint64_t workspace_bytes, void* stream);
 uint64_t grt_photon_emit_workspace_bytes(int32_t count);
+/* grt_photon_load_dev builds the map on the CURRENT device, where d_pos4 / d_pow4 live; it does not
+ * switch devices (opts->first_device is not consulted). */
 int grt_photon_load_dev(const grt_opts* opts, const float* d_pos4, const float* d_pow4, int32_t n,
                         float power_scale, uint64_t emitted, grt_pmap** out);
 /* Lights as NewScene derives them (scene.go:42-46): how many, and int(lightArea / area) of

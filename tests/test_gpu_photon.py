@@ -198,3 +198,47 @@ def test_photon_mapped_trace_matches_oracle(pkg, ob):
     img = px.reshape(H, W, 4)[..., 2::-1].astype(np.float64)             # B,G,R -> R,G,B
     want = np.floor(255.99 * np.minimum(1.0, np.sqrt(a)))
     assert (np.abs(img - want) <= 1).mean() > 0.999
+
+
+def test_load_dev_builds_on_the_current_device(pkg):
+    """grt_photon_load_dev follows the "_dev" contract: the map is built on the CURRENT device,
+    where the caller's arrays live, and the current device is not switched — under one process per GPU rank
+    r's arrays are on GPU r, whatever opts.first_device says.  Host-buffer entry points select a device and
+    put the caller's back."""
+    import importlib
+    import torch
+
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    scene = pkg.scenes.cornell(32, 32, "cornell8d")
+    cur = torch.cuda.current_device()
+    m = shard.build_photon_map_sharded(scene, 3000, False, 0, 1, seed=2)
+    assert m.device() == cur and torch.cuda.current_device() == cur and m.count() == 3000
+    ref = pkg.tracer.PhotonMap(3000).build(scene, seed=2)
+    assert ref.device() == 0 and torch.cuda.current_device() == cur
+    for a, b in zip(m.read(), ref.read()):
+        assert (a == b).all()
+    assert torch.cuda.current_device() == cur
+
+
+def test_load_dev_on_a_second_gpu(pkg):
+    """The same with current device 1 (skipped on a one-GPU box): the sharded build must not touch GPU 0."""
+    import importlib
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    shard = importlib.import_module("go-raytracer_amd.shard")
+    scene = pkg.scenes.cornell(32, 32, "cornell8d")
+    ref = pkg.tracer.PhotonMap(3000).build(scene, seed=2)              # host entry point: opts.first_device = 0
+    with torch.cuda.device(1):
+        m = shard.build_photon_map_sharded(scene, 3000, False, 0, 1, seed=2)
+        assert m.device() == 1 and torch.cuda.current_device() == 1
+        q = torch.rand(64, 3, device="cuda") * 555
+        out = torch.empty_like(q)
+        pkg._capi.check(pkg._capi.load().grt_photon_gather_dev(m.handle, q.data_ptr(), q.data_ptr(), 64, 0.0, 50, out.data_ptr(), None,
+                                                               torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+    for a, b in zip(m.read(), ref.read()):
+        assert (a == b).all()
+    assert torch.cuda.current_device() == 0

@@ -16,6 +16,43 @@ from conftest import ROOT
 W, H, SPP = 40, 52, 2  # 52 rows = 6 full bands + one 4-row band: ragged on purpose
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(target, world, n_results):
+    """Start `world` ranks, collect n_results queue items; a rank that dies before it reports (import error,
+    failed assert, rendezvous trouble) fails the test instead of blocking it."""
+    import queue as _q
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = []
+    try:
+        while len(out) < n_results:
+            try:
+                out.append(q.get(timeout=2.0))
+            except _q.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"a rank exited with {dead} before reporting"
+                assert any(p.is_alive() for p in procs) or not q.empty(), "all ranks ended without reporting"
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    return out
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,16 +78,7 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_frame_equals_single_process(pkg, ob, world):
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 29500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    frame = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    frame, = run_ranks(_worker, world, 1)
     full = ob.OracleScene(pkg.scenes.cornell_flat(W, H)).RenderAccum(SPP, seed=5).astype(np.float32)
     assert frame.shape == (H, W, 3) and (frame == full).all()  # exact: result independent of G
 
@@ -101,16 +129,7 @@ def test_sample_range_reduce_equals_single_process(world):
             parts = [shard.sample_range(spp, r, g) for r in range(g)]
             assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(g - 1))
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 31500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_sample_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    frame, full = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    (frame, full), = run_ranks(_sample_worker, world, 1)
     np.testing.assert_allclose(frame, full, rtol=1e-6, atol=1e-7)
 
 
@@ -137,16 +156,7 @@ def _slice_worker(rank, world, port, q):
 def test_photon_slices_gather_in_emission_order(world):
     """Photon-build sharding: the ranks' stored photons concatenate in rank order with global
     emission offsets rank * slice + local offset, identically on every rank."""
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 33500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_slice_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get() for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = sorted(run_ranks(_slice_worker, world, world), key=lambda t: t[0])
     want_pos = np.concatenate([r[3] for r in res])
     want_off = np.concatenate([r[4].astype(np.int64) + r[0] * 16 for r in res])
     for r in res:

@@ -75,7 +75,7 @@ if a.cpu_queries > 0:
     gp, gw, gt = gmap.read()
     o = ob.OraclePhotonMap.load(gp.astype(np.float64), gw.astype(np.float64), gt)
     sel = np.random.RandomState(0).choice(nq, min(a.cpu_queries, nq), replace=False)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = importlib.import_module("bench").host_cpu_share()[0] + 1   # NumCPU()+1 workers (scene.go:106)
     t0 = time.perf_counter()
     o.gather(P[sel].astype(np.float64), N[sel].astype(np.float64), 0.0, a.k, nthreads=threads)
     dt = time.perf_counter() - t0

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Config C5: synthetic N-sphere scene (SURVEY.md §8d `spheres1M`) at 1920x1080, 256 spp, through
-the bounding-volume hierarchy.  Single GPU here; `--gpus N` under torch.distributed.run shards the
-SAMPLE range over the ranks and sums the FP32 frames with one RCCL reduce.
-    python tools/bench_spheres.py [--spheres 1000000] [--spp 256] [--steps 3]
+the bounding-volume hierarchy.  `--gpus N` (N > 1: the script starts its N ranks itself, or runs under
+torch.distributed.run) shards the SAMPLE range over the ranks and sums the FP32 frames with one RCCL reduce.
+    python tools/bench_spheres.py [--spheres 1000000] [--spp 256] [--steps 3] [--gpus N]
 Prints one JSON line (rank 0)."""
 import argparse
 import ctypes as C
@@ -12,12 +12,7 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-pkg = importlib.import_module("go-raytracer_amd")
-shard = importlib.import_module("go-raytracer_amd.shard")
 ap = argparse.ArgumentParser()
 ap.add_argument("--spheres", type=int, default=1000000)
 ap.add_argument("--spp", type=int, default=256)
@@ -29,7 +24,18 @@ ap.add_argument("--cpu-spheres", type=int, default=10000)
 ap.add_argument("--chunk-spp", type=int, default=0, help="samples per wave item (0 = the library's choice)")
 ap.add_argument("--as-boxes", action="store_true", help="every sphere exported as its bounding AABB (SURVEY.md §8d)")
 a = ap.parse_args()
+_rc = importlib.import_module("go-raytracer_amd.launch").self_launch(__file__, sys.argv[1:], a.gpus)   # before any GPU call
+if _rc is not None:
+    raise SystemExit(_rc)
+
+import numpy as np  # noqa: E402,F401
+import torch  # noqa: E402
+
+pkg = importlib.import_module("go-raytracer_amd")
+shard = importlib.import_module("go-raytracer_amd.shard")
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world != a.gpus:
+    raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 dev = torch.device("cuda", torch.cuda.current_device())
 if world > 1:
@@ -94,7 +100,7 @@ if rank == 0:
     if a.cpu_spheres > 0 and world == 1:
         from oracle import binding as ob
         cw, ch, cspp = 640, 360, 8
-        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+        threads = importlib.import_module("bench").host_cpu_share()[0] + 1   # NumCPU()+1 workers (scene.go:106)
         o = ob.OracleScene(pkg.scenes.spheres_flat(a.cpu_spheres, cw, ch))
         t0 = time.perf_counter()
         o.RenderAccum(cspp, seed=1, nthreads=threads)
