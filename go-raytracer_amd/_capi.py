@@ -67,6 +67,7 @@ PROTOTYPES = {
     "grt_render_accum_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32, _vp, _vp,
                                        C.c_uint64, _vp, _vp]),
     "grt_render_accum_samples_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "grt_render_accum_noalloc_dev": (C.c_int, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "grt_shard_rows": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "grt_accum_workspace_bytes": (C.c_uint64, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32]),
     "grt_tonemap_dev": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),

@@ -68,6 +68,35 @@ GRT_API double grt_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint3
   return grt_rng_draw64(grt_rng_path_key(grt_rng_pixel_key(grt_rng_seed32(seed), pixel), sample), dim);
 }
 
+// ---- library scratch for the entry point that allocates nothing ---------------------------
+// grt_render_accum_noalloc_dev keeps the per-chunk partial sums (the "partial sums" buffer of DESIGN.md §4,
+// which grt_render_accum_dev takes from the caller's workspace) in this file-scope device array.  Every GPU
+// the library runs on holds its own copy, at its own address, until the process ends.  In host code the
+// array's NAME is only a stand-in: the device address comes from hipGetSymbolAddress, asked once per device
+// with that device current, and is what kernels and memsets are given.
+// (GRT_NOALLOC_SCRATCH_BYTES: include/grt.h)
+#define GRT_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[GRT_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[GRT_NOALLOC_MAX_DEVICES] = {};
+
+// The current device's copy of `scratch`.  First call on a device: resolves and keeps the address
+// (stage() calls this when a scene is staged on a device, so a later no-alloc call only reads the table).
+static int scratch_of_current_device(void** out) {
+  int dev = 0;
+  GRT_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= GRT_NOALLOC_MAX_DEVICES) return grt_fail(GRT_ELIMIT, "device ordinal %d beyond %d", dev, GRT_NOALLOC_MAX_DEVICES - 1);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    GRT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return grt_fail(GRT_EHIP, "hipGetSymbolAddress(scratch) returned NULL on device %d", dev);
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GRT_OK;
+}
+
 // ---- scene staging ---------------------------------------------------------------------
 static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_prims, const grt_material* mats,
                           int n_mats) {
@@ -507,7 +536,11 @@ static int stage(grt_scene* s, DeviceScene& out) {
     clk.lap("tile culling");
     return GRT_OK;
   };
-  const int rc = upload();
+  int rc = upload();
+  if (!rc) {  // set-up for grt_render_accum_noalloc_dev: this device's address of the library scratch
+    void* unused = nullptr;
+    rc = scratch_of_current_device(&unused);
+  }
   if (rc) {  // nothing of a scene that could not be staged stays on the device
     free_device_scene(d);
     return rc;
@@ -708,6 +741,49 @@ GRT_API int grt_render_accum_samples_dev(grt_scene* s, const grt_opts* o, int32_
                                  nullptr, nullptr, nullptr, 0);
 } catch (...) {
   return grt_fail_exception("grt_render_accum_samples_dev");
+}
+
+// grt_render_accum_dev for callers that cannot allocate (HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): no workspace argument, the per-chunk partial sums live in the library's `scratch`.
+// Calls no hipMalloc / hipFree / allocating routine: the scene must already be staged on the current device
+// (any earlier render or parity call on that device stages it), else GRT_EINVAL.  Chunking: with
+// opts->chunk_spp == 0 the library's choice is coarsened until the slabs fit GRT_NOALLOC_SCRATCH_BYTES (one
+// chunk needs no scratch at all); an explicit chunk_spp whose slabs do not fit is refused with GRT_ELIMIT.
+// For the same chunk size the frame equals grt_render_accum_dev's bit for bit (same kernels, same order of
+// the chunk sums).  Every pixel of every slab is written before k_sum_chunks reads it, so nothing of the
+// previous call's contents has to be cleared.  All calls on one GPU share that GPU's array: calls that
+// overlap there (two streams, two threads) race.
+GRT_API int grt_render_accum_noalloc_dev(grt_scene* s, const grt_opts* o, int32_t shard, int32_t n_shards, int32_t samples,
+                                         float* d_rgb_sum, uint64_t* d_ray_count, void* stream) try {
+  if (!s || !d_rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_noalloc_dev: NULL scene or output");
+  int dev = 0;
+  GRT_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->dev.find(dev) == s->dev.end())
+      return grt_fail(GRT_EINVAL, "grt_render_accum_noalloc_dev: the scene is not staged on device %d (staging allocates: render once "
+                                  "with grt_render_accum_dev on this device first)", dev);
+  }
+  grt_opts opts = o ? *o : grt_opts{0, 0, 1, 0, 0};
+  uint64_t need = grt_accum_workspace_bytes(s, &opts, shard, n_shards, samples);
+  if (need > GRT_NOALLOC_SCRATCH_BYTES) {
+    if (opts.chunk_spp > 0)
+      return grt_fail(GRT_ELIMIT, "grt_render_accum_noalloc_dev: chunk_spp %d needs %llu bytes of partial sums, the library scratch holds %llu "
+                                  "(raise chunk_spp, or pass 0 for a choice that fits)", opts.chunk_spp, (unsigned long long)need,
+                      (unsigned long long)GRT_NOALLOC_SCRATCH_BYTES);
+    const uint64_t slab = (uint64_t)grt_shard_rows(s->d.height, shard, n_shards) * (uint64_t)s->d.width * 3u * sizeof(float);
+    const int fit = slab ? (int)(GRT_NOALLOC_SCRATCH_BYTES / slab) : 1;  // chunks whose slabs fit
+    opts.chunk_spp = fit >= 2 ? (samples + fit - 1) / fit : samples;     // fit < 2: one chunk, written straight to d_rgb_sum
+    need = grt_accum_workspace_bytes(s, &opts, shard, n_shards, samples);
+    if (need > GRT_NOALLOC_SCRATCH_BYTES) return grt_fail(GRT_ELIMIT, "grt_render_accum_noalloc_dev: internal: %llu bytes do not fit", (unsigned long long)need);
+  }
+  void* ptr = nullptr;
+  int rc = scratch_of_current_device(&ptr);  // resolved when the scene was staged: a table read
+  if (rc) return rc;
+  return grt_render_dev_internal(s, &opts, shard, n_shards, 0, samples, d_rgb_sum, ptr, GRT_NOALLOC_SCRATCH_BYTES, d_ray_count, stream,
+                                 nullptr, nullptr, nullptr, 0);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_noalloc_dev");
 }
 
 // total (+)= frame + photon term of one batch (k_pm_accumulate); used by grt_photon.hip

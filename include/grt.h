@@ -158,6 +158,19 @@ int grt_render_accum_dev(grt_scene* scene, const grt_opts* opts, int32_t shard, 
 int grt_render_accum_samples_dev(grt_scene* scene, const grt_opts* opts, int32_t sample_first,
                                  int32_t samples, float* d_rgb_sum, void* d_workspace,
                                  uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream);
+/* grt_render_accum_dev for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  Same inputs and outputs as grt_render_accum_dev minus the workspace: the per-chunk
+ * partial sums live in a file-scope device array of the library, GRT_NOALLOC_SCRATCH_BYTES (64 MiB) per GPU,
+ * held until the process ends.  Calls no hipMalloc / hipFree.  The scene must already be staged on the
+ * CURRENT device (any earlier render on that device does it), else GRT_EINVAL.  opts->chunk_spp == 0: the
+ * library's chunk size, coarsened until the slabs (n_chunks * grt_shard_rows * width * 12 B) fit; an explicit
+ * chunk_spp whose slabs exceed the scratch is refused with GRT_ELIMIT.  At equal chunk size the frame equals
+ * grt_render_accum_dev's bit for bit.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU race. */
+#define GRT_NOALLOC_SCRATCH_BYTES ((uint64_t)64 << 20)
+int grt_render_accum_noalloc_dev(grt_scene* scene, const grt_opts* opts, int32_t shard, int32_t n_shards,
+                                 int32_t samples, float* d_rgb_sum, uint64_t* d_ray_count, void* stream);
 int32_t grt_shard_rows(int32_t height, int32_t shard, int32_t n_shards);
 uint64_t grt_accum_workspace_bytes(const grt_scene* scene, const grt_opts* opts, int32_t shard,
                                    int32_t n_shards, int32_t samples);
