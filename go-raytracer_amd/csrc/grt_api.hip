@@ -473,7 +473,7 @@ static int stage(grt_scene* s, DeviceScene& out) {
   StageClock clk;
   const size_t np = s->prims.size(), nm = s->mats.size(), nl = s->lights.size();
   // object and material tables are padded to GRT_FAST_PRIMS records (never-hit spheres / zero materials) so the register-resident kernel loads them whole
-  std::vector<float4> hp(2 * std::max<size_t>(np, GRT_FAST_PRIMS)), hm(2 * std::max<size_t>(nm, GRT_FAST_PRIMS)),
+  std::vector<float4> hp(2 * std::max<size_t>(np, GRT_FAST_PRIMS)), hm(GRT_MAT_STRIDE * std::max<size_t>(nm, GRT_FAST_PRIMS)),
       hl(2 * std::max<size_t>(nl, 1));
   for (size_t i = np; i < hp.size() / 2; ++i) {  // never-hit padding: a sphere with R^2 = -1
     hp[2 * i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -502,8 +502,12 @@ static int stage(grt_scene* s, DeviceScene& out) {
     int flags = (m.transparent ? GRT_MAT_TRANSPARENT : 0) | (m.lambert ? GRT_MAT_LAMBERT : 0) | (m.normal ? GRT_MAT_NORMAL : 0);
     float w;
     memcpy(&w, &flags, 4);
-    hm[2 * i] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], (float)m.refr_index);
-    hm[2 * i + 1] = make_float4((float)m.reflectivity, (float)m.roughness, (float)m.emittance, w);
+    hm[GRT_MAT_STRIDE * i] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], (float)m.refr_index);
+    hm[GRT_MAT_STRIDE * i + 1] = make_float4((float)m.reflectivity, (float)m.roughness, (float)m.emittance, w);
+    // Refract's constants (vec3.go:134-159; refrRatio = 1/RefrIndex, scene.go:296-297) in float64, rounded once
+    const double ratio = 1.0 / m.refr_index, flipped = 1.0 / ratio;
+    const double r0a = (1.0 - ratio) / (1.0 + ratio), r0b = (1.0 - flipped) / (1.0 + flipped);
+    hm[GRT_MAT_STRIDE * i + 2] = make_float4((float)ratio, (float)flipped, (float)(r0a * r0a), (float)(r0b * r0b));
   }
   for (size_t k = 0; k < nl; ++k) {
     const grt_prim& p = s->prims[s->lights[k]];
@@ -644,6 +648,7 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->inner_again = e ? std::max(1, std::min(65, atoi(e))) : 1;
   e = getenv("GRT_BVH_INNER_RUN");
   j->inner_run = e ? std::max(1, std::min(64, atoi(e))) : 4;
+  j->no_octants = (o && (o->flags & 15) == 7) ? 1 : 0;  // variant 7: the min/max slab test (A/B against the octant tables)
   return GRT_OK;
 }
 
@@ -1083,16 +1088,16 @@ GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t sampl
   const int tiles = ((ks.W + 7) / 8) * ((ks.H + 7) / 8);
   if (s->use_bvh)
     hipLaunchKernelGGL(k_primary_sweep<-1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
-                       d_checksum);
+                       d_checksum, 0);
   else if (scene_is_small(s) && o && (o->flags & 15) == 3)
     hipLaunchKernelGGL((k_primary_sweep<GRT_FAST_PRIMS, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ks, samples, d_checksum);
+                       ks, samples, d_checksum, 0);
   else if (scene_is_small(s) && !(o && (o->flags & 15) == 1))
     hipLaunchKernelGGL((k_primary_sweep<GRT_FAST_PRIMS, false>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ks, samples, d_checksum);
+                       ks, samples, d_checksum, (o && (o->flags & 15) == 7) ? 1 : 0);
   else
     hipLaunchKernelGGL(k_primary_sweep<0>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
-                       d_checksum);
+                       d_checksum, 0);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
 } catch (...) {

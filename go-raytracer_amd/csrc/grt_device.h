@@ -62,9 +62,11 @@ GRT_DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 // prims[2i+1] = (b.x, b.y, b.z, bits)            box MaxBound  | sphere: b.x = radius^2
 //               bits (int): bit0 kind (1 = AABB), bit1 emissive (Emittance > 0), bit2 transparent,
 //               mat << 8
-// mats[2m]    = (r, g, b, refr_index)
-// mats[2m+1]  = (reflectivity, roughness, emittance, flags)   flags: 1 transparent,
+// mats[3m]    = (r, g, b, refr_index)
+// mats[3m+1]  = (reflectivity, roughness, emittance, flags)   flags: 1 transparent,
 //               2 lambert, 4 normal
+// mats[3m+2]  = what Refract (vec3.go:134-159) derives from the index alone, in float64 on the host:
+//               (ratio = 1/RefrIndex, 1/ratio, Schlick r0 of ratio, r0 of 1/ratio)
 // lights[2k]  = (Pos().xyz, prim index as a float), lights[2k+1] = (Color.rgb, prim index as int bits)   scene.go:42-46;
 //               in ascending prim index (NewScene appends in object order)
 struct KCamera {
@@ -97,6 +99,7 @@ struct KScene {
   const uint8_t* __restrict__ tile_live;
 };
 
+#define GRT_MAT_STRIDE 3
 #define GRT_MAT_TRANSPARENT 1
 #define GRT_MAT_LAMBERT 2
 #define GRT_MAT_NORMAL 4
@@ -311,26 +314,26 @@ GRT_DEV f3 sample_hemi32(f3 n, float u1, float u2) {
   return mk3(fmaf(u.x, c, fmaf(v.x, s, n.x * w)), fmaf(u.y, c, fmaf(v.y, s, n.y * w)),
              fmaf(u.z, c, fmaf(v.z, s, n.z * w)));
 }
-GRT_DEV f3 reflect32(f3 v, f3 n) { return unit3(fma3(n, -2.0f * dot3(v, n), v)); }  // vec3.go:129-131
-// Vec3.Refract (vec3.go:134-159); xi replaces rand.Float64() of vec3.go:152.
-GRT_DEV bool refract32(f3 v, f3 n, float eta_ratio, float xi, f3& out) {
-  float ratio = eta_ratio;
-  f3 rn = n;
-  if (dot3(v, n) >= 0.0f) {
-    rn = -n;
-    ratio = rcp32(ratio);
-  }
+// vec3.go:129-131.  v and n are unit vectors, so v - 2(v.n)n is unit to rounding; the reference's Unit() is not
+// repeated (as in sample_hemi32).
+GRT_DEV f3 reflect32(f3 v, f3 n) { return fma3(n, -2.0f * dot3(v, n), v); }
+// Vec3.Refract (vec3.go:134-159); xi replaces rand.Float64() of vec3.go:152.  m2 = the material's third record:
+// ratio, 1/ratio and r0 = ((1-ratio)/(1+ratio))^2 for both orientations (no reciprocal in the kernel).  The
+// refracted direction r1 + r2 has |r1|^2 + |r2|^2 = 1 by construction: not normalised again.
+GRT_DEV bool refract32(f3 v, f3 n, float4 m2, float xi, f3& out) {
+  const bool flip = dot3(v, n) >= 0.0f;
+  const float ratio = flip ? m2.y : m2.x;
+  float r0 = flip ? m2.w : m2.z;
+  const f3 rn = flip ? -n : n;
   float cosi = fminf(-dot3(v, rn), 1.0f);
   float sini = sqrt32(1.0f - cosi * cosi);
   bool tir = ratio * sini > 1.0f;
-  float r0 = (1.0f - ratio) * rcp32(1.0f + ratio);
-  r0 = r0 * r0;
-  float m = 1.0f - cosi, m2 = m * m;
-  r0 = fmaf(1.0f - r0, m2 * m2 * m, r0);
+  float m = 1.0f - cosi, mm = m * m;
+  r0 = fmaf(1.0f - r0, mm * mm * m, r0);
   if (tir | (r0 > xi)) return false;
   f3 r1 = fma3(rn, cosi, v) * ratio;
   float k = -sqrt32(fabsf(1.0f - dot3(r1, r1)));
-  out = unit3(fma3(rn, k, r1));
+  out = fma3(rn, k, r1);
   return true;
 }
 
@@ -445,6 +448,90 @@ GRT_DEV int intersect_lds(const float4* __restrict__ tp, uint32_t box_mask, cons
   return best;
 }
 
+// ---- the same loop over direction-sorted box bounds ----------------------------------------
+// AABB.Hit orders the two slab distances of every axis with min/max (aabb.go:29): which bound is the near
+// one depends only on the sign of the direction component.  The LDS holds the objects once per direction
+// octant with the box bounds already in (near, far) order; a lane reads the table of ITS ray's octant (bit k
+// of the octant = sign bit of D.k), so the per-axis min/max disappear: near = 3 FMA, far = 3 FMA, then one
+// v_max3, one v_min3 and the two clamps against bias and tbest.  Same values bit for bit: for inv > 0 and
+// lo <= hi, fma(lo, inv, c) <= fma(hi, inv, c) (rounding is monotone), so min(x0, x1) IS the near product.
+// Rays with a zero direction component never come here (the wave takes the Go NaN/Inf path).
+// Record of object i in an octant's table (8 floats): box (n.x, n.y, n.z, f.x, f.y, f.z, -, -),
+// sphere (c.x, c.y, c.z, R^2, ...).  Consecutive tables are GRT_OCT_STRIDE(NP) floats apart: 16 bytes more
+// than the records take, so that the 8 tables' copies of one record lie in 8 different groups of 4 LDS banks
+// and a wave whose lanes look into all 8 octants still reads without a bank conflict.
+#define GRT_OCT_STRIDE(NP) (8 * (NP) + 4)
+GRT_DEV int ray_octant(f3 D) {
+  return (int)((__float_as_uint(D.x) >> 31) | ((__float_as_uint(D.y) >> 31) << 1) | ((__float_as_uint(D.z) >> 31) << 2));
+}
+// One record of an octant table from the staged object record (pa, pb).
+GRT_DEV void octant_record(float4 pa, float4 pb, int oct, float* q) {
+  if (__float_as_int(pb.w) & 1) {
+    const float lx = fminf(pa.x, pb.x), hx = fmaxf(pa.x, pb.x), ly = fminf(pa.y, pb.y), hy = fmaxf(pa.y, pb.y);
+    const float lz = fminf(pa.z, pb.z), hz = fmaxf(pa.z, pb.z);
+    q[0] = (oct & 1) ? hx : lx, q[1] = (oct & 2) ? hy : ly, q[2] = (oct & 4) ? hz : lz;
+    q[3] = (oct & 1) ? lx : hx, q[4] = (oct & 2) ? ly : hy, q[5] = (oct & 4) ? lz : hz;
+    q[6] = 0.0f, q[7] = 0.0f;
+  } else {
+    q[0] = pa.x, q[1] = pa.y, q[2] = pa.z, q[3] = pb.x;
+    q[4] = 0.0f, q[5] = 0.0f, q[6] = 0.0f, q[7] = 0.0f;
+  }
+}
+// v_min / v_max / v_min3 as the instructions themselves.  fminf / fmaxf go through llvm.minnum / maxnum, which in
+// IEEE mode must quiet a signalling NaN first: the compiler puts a v_max_f32 x, x in front of every operand it
+// cannot prove canonical — tbest (a select) and bias (a kernel argument), two extra instructions per box.  No
+// operand here can be a signalling NaN (FMA results, a select of computed distances, finite scene data).
+GRT_DEV float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+GRT_DEV float vmax_f32_s(float uniform, float b) {  // first operand wave-uniform (an SGPR)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b));
+  return r;
+}
+GRT_DEV float vmin3_f32(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+GRT_DEV void hit_update_oct(const float* __restrict__ q, bool is_box, int i, const Ray32& r, float bias, float& tbest, int& best) {
+  const float4 qa = *(const float4*)q;
+  if (is_box) {
+    const float2 qb = *(const float2*)(q + 4);
+    const float nx = fmaf(qa.x, r.invD.x, -r.OinvD.x), ny = fmaf(qa.y, r.invD.y, -r.OinvD.y), nz = fmaf(qa.z, r.invD.z, -r.OinvD.z);
+    const float fx = fmaf(qa.w, r.invD.x, -r.OinvD.x), fy = fmaf(qb.x, r.invD.y, -r.OinvD.y), fz = fmaf(qb.y, r.invD.z, -r.OinvD.z);
+    const float t0 = fmaxf(fmaxf(nx, ny), nz);                    // v_max3
+    const float lo = vmax_f32_s(bias, t0);
+    const float hi = vmin3_f32(fx, fy, vmin_f32(fz, tbest));
+    const bool acc = (hi > lo) & (t0 > 0.0f);                     // aabb.go:33-44, scene.go:174
+    tbest = acc ? t0 : tbest;
+    best = acc ? i : best;
+  } else {
+    f3 oc = mk3(r.O.x - qa.x, r.O.y - qa.y, r.O.z - qa.z);
+    float k = dot3(oc, r.D) * r.inva;
+    f3 l = fma3(r.D, -k, oc);
+    float sq = sqrt32((qa.w - dot3(l, l)) * r.inva);  // NaN when there is no real root
+    float t1 = -k - sq, t2 = -k + sq;
+    const bool in1 = (t1 > bias) & (t1 < tbest), in2 = (t2 > bias) & (t2 < tbest);
+    const float t = in1 ? t1 : t2;
+    const bool acc = (in1 | in2) & (t > 0.0f);
+    tbest = acc ? t : tbest;
+    best = acc ? i : best;
+  }
+}
+// oct: the lane's octant table (oct_tables + ray_octant(D) * GRT_OCT_STRIDE(NP))
+template <int NP>
+GRT_DEV int intersect_lds_oct(const float* __restrict__ oct, uint32_t box_mask, const Ray32& r, float bias, float& t_out) {
+  float tbest = 3.402823466e38f;
+  int best = -1;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) hit_update_oct(oct + 8 * i, (box_mask >> i) & 1u, i, r, bias, tbest, best);
+  t_out = tbest;
+  return best;
+}
+
 // Surface(p) from an already fetched object record (see surface32).
 GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3& n) {
   int bits = __float_as_int(pb.w);
@@ -458,6 +545,35 @@ GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3
     p.y = ax1 ? (r.D.y > 0.0f ? pa.y : pb.y) : p.y;
     p.z = ax2 ? (r.D.z > 0.0f ? pa.z : pb.z) : p.z;
     const float eps = 1e-4f;  // aabb.go:56; the cascade of aabb.go:57-70 without branches
+    const bool x0 = p.x - pa.x < eps, x1 = pb.x - p.x < eps, y0 = p.y - pa.y < eps, y1 = pb.y - p.y < eps;
+    const bool z0 = p.z - pa.z < eps, z1 = pb.z - p.z < eps;
+    const bool cx = x0 | x1, cy = !cx & (y0 | y1), cz = !cx & !(y0 | y1) & (z0 | z1);
+    n.x = cx ? (x0 ? -1.0f : 1.0f) : 0.0f;
+    n.y = cy ? (y0 ? -1.0f : 1.0f) : 0.0f;
+    n.z = cz ? (z0 ? -1.0f : 1.0f) : 0.0f;
+  } else {
+    f3 d = mk3(p.x - pa.x, p.y - pa.y, p.z - pa.z);
+    float s = rsq32(dot3(d, d));
+    n = d * (pa.w < 0.0f ? -s : s);
+  }
+  return bits >> 8;
+}
+
+// Surface(p) of a box from its record in the lane's octant table (intersect_lds_oct): the three near slab
+// distances are the very values the loop took its max3 of, so the entry axis is the one that produced t (first
+// axis on ties), and the near bound of that axis is the face the hit point is snapped to.  The epsilon cascade
+// of aabb.go:57-70 runs on MinBound / MaxBound (pa, pb) as in the reference.
+GRT_DEV int surface_rec_oct(float4 pa, float4 pb, const float* __restrict__ q, const Ray32& r, float t, f3& p, f3& n) {
+  const int bits = __float_as_int(pb.w);
+  p = fma3(r.D, t, r.O);
+  if (bits & 1) {
+    const float4 qa = *(const float4*)q;
+    const float nx = fmaf(qa.x, r.invD.x, -r.OinvD.x), ny = fmaf(qa.y, r.invD.y, -r.OinvD.y), nz = fmaf(qa.z, r.invD.z, -r.OinvD.z);
+    const bool ax0 = (nx >= ny) & (nx >= nz), ax1 = !ax0 & (ny >= nz), ax2 = !ax0 & !ax1;
+    p.x = ax0 ? qa.x : p.x;
+    p.y = ax1 ? qa.y : p.y;
+    p.z = ax2 ? qa.z : p.z;
+    const float eps = 1e-4f;  // aabb.go:56
     const bool x0 = p.x - pa.x < eps, x1 = pb.x - p.x < eps, y0 = p.y - pa.y < eps, y1 = pb.y - p.y < eps;
     const bool z0 = p.z - pa.z < eps, z1 = pb.z - p.z < eps;
     const bool cx = x0 | x1, cy = !cx & (y0 | y1), cz = !cx & !(y0 | y1) & (z0 | z1);
@@ -576,7 +692,7 @@ template <bool QUEUE, int DIRECT = 0>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t,
                         WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, int* bvh_stack = nullptr,
-                        int bvh_stride = 0);
+                        int bvh_stride = 0, const float* octq = nullptr);
 
 // One level of trace() for one lane.  NP > 0: tp (objects) and tm (materials) are LDS copies
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
@@ -586,7 +702,7 @@ template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                           uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr,
                           WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, const float4* ts = nullptr,
-                          int n_boxes = 0) {
+                          int n_boxes = 0, const float* oct = nullptr) {
   // RELOAD: forbid hoisting the LDS object reads out of the wave loop (keeps them out of
   // long-lived VGPRs: more waves per SIMD, 16 ds_read_b128 per level)
   if (RELOAD && NP > 0) asm volatile("" ::: "memory");
@@ -594,6 +710,7 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   ray_setup_unit(r, L.O, L.D);
   float t;
   int id;
+  const float* octq = nullptr;  // the lane's direction-octant table (scenes of <= 8 objects)
   if (NP < 0)  // NP < 0: bounding-volume hierarchy (grt_bvh.h), per-lane stack in LDS
     id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256)
                                 : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack, 256);
@@ -601,12 +718,14 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
     id = __any(ray_has_zero(r)) ? intersect_tab_t<true>(tp, S.n_prims, S.bias, r, t) : intersect_sorted(ts, n_boxes, S.n_prims, S.bias, r, t);
   else if (__builtin_expect(__any(ray_has_zero(r)), 0))
     id = intersect32_t<true>(S, r, t);  // Go NaN/Inf rules, objects from memory (rare)
+  else if (NP > 0 && oct)
+    id = intersect_lds_oct<(NP > 0 ? NP : 1)>(octq = oct + ray_octant(r.D) * GRT_OCT_STRIDE(NP > 0 ? NP : 1), S.box_mask, r, S.bias, t);
   else if (NP > 0)
     id = intersect_lds<NP, PREFETCH>(tp, S.box_mask, r, S.bias, t);
   else
     id = intersect32_t<false>(S, r, t);
   n_rays++;                                         // scene.go:242
-  path_shade<QUEUE, NP < 0 ? 2 : 0>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base, bvh_stack, 256);
+  path_shade<QUEUE, NP < 0 ? 2 : 0>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base, bvh_stack, 256, octq);
 }
 
 // Everything of one trace() level after intersect(): Surface, material dispatch, the radiance a
@@ -614,13 +733,13 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
 template <bool QUEUE, int DIRECT>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
-                        const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride) {
+                        const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride, const float* octq) {
   const bool hit = id >= 0;                         // scene.go:244
   const int idc = hit ? id : 0;
   const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];
   f3 p, n;
-  const int m = surface_rec(pa, pb, r, t, p, n);    // scene.go:254-255
-  const float4 m0 = tm[2 * m], m1 = tm[2 * m + 1];
+  const int m = octq ? surface_rec_oct(pa, pb, octq + 8 * idc, r, t, p, n) : surface_rec(pa, pb, r, t, p, n);  // scene.go:254-255
+  const float4 m0 = tm[GRT_MAT_STRIDE * m], m1 = tm[GRT_MAT_STRIDE * m + 1];
   const int flags = __float_as_int(m1.w);
   const f3 color = mk3(m0.x, m0.y, m0.z);
   // material priority of scene.go:274-305: Normal, Emittance, Lambert, Reflectivity, Transparent, diffuse
@@ -707,7 +826,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
       L.thr = L.thr * (color * m1.x);
     } else {                                        // scene.go:295-304; u1 is the roulette draw
       f3 d;
-      if (!refract32(r.D, n, rcp32(m0.w), u1, d)) d = reflect32(r.D, n);
+      if (!refract32(r.D, n, tm[GRT_MAT_STRIDE * m + 2], u1, d)) d = reflect32(r.D, n);
       L.D = d;
     }
   }

@@ -26,6 +26,7 @@ struct RenderJob {
   int inner_weight;     // hierarchy scenes: an inner-node step runs when inner lanes * this >= leaf lanes * 4
   int inner_again;      // hierarchy scenes: another inner-node step follows at once while this many lanes still hold one ...
   int inner_run;        // ... up to this many steps per scheduling round
+  int no_octants;       // A/B: scenes of <= 8 objects through the min/max slab test instead of the direction-octant tables
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -51,17 +52,18 @@ struct SceneTables {
   const float4* tm;
   const float4* ts = nullptr;  // mid-size scenes: the objects sorted by kind (intersect_sorted)
   int n_boxes = 0;
+  const float* oct = nullptr;  // NP > 0: the 8 direction-octant tables (intersect_lds_oct)
 };
 
 // The host pads the staged arrays to GRT_FAST_PRIMS records, so the copies are unconditional.
 template <int NP, bool LDSGEN = false>
-GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
+GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T, float* oct = nullptr) {
   if (NP == 0 && LDSGEN) {
-    // [0, 2N) objects in index order (Surface and material of the hit), [2N, 4N) materials,
-    // [4N, 6N) objects sorted by kind: a stable partition by the first wave (ballot + mbcnt)
+    // [0, 2N) objects in index order (Surface and material of the hit), [2N, 5N) materials,
+    // [5N, 7N) objects sorted by kind: a stable partition by the first wave (ballot + mbcnt)
     for (int i = threadIdx.x; i < 2 * S.n_prims; i += blockDim.x) lds[i] = S.prims[i];
-    for (int i = threadIdx.x; i < 2 * S.n_mats; i += blockDim.x) lds[2 * GRT_LDS_PRIMS + i] = S.mats[i];
-    float4* sorted = lds + 4 * GRT_LDS_PRIMS;
+    for (int i = threadIdx.x; i < GRT_MAT_STRIDE * S.n_mats; i += blockDim.x) lds[2 * GRT_LDS_PRIMS + i] = S.mats[i];
+    float4* sorted = lds + (2 + GRT_MAT_STRIDE) * GRT_LDS_PRIMS;
     int n_boxes = 0;
     for (int base = 0; base < S.n_prims; base += 64) {  // every wave counts (uniform), the first one writes
       const int i = base + (threadIdx.x & 63);
@@ -92,15 +94,19 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T) {
     T.ts = sorted;
     T.n_boxes = n_boxes;
   } else if (NP > 0) {
-    // [0, 2NP) objects, [2NP, 4NP) materials (a scene never has more materials than objects
+    // [0, 2NP) objects, [2NP, 5NP) materials (a scene never has more materials than objects
     // after de-duplication; the host checks n_mats <= NP before choosing this kernel)
-    for (int i = threadIdx.x; i < 2 * NP; i += blockDim.x) {
-      lds[i] = S.prims[i];
+    for (int i = threadIdx.x; i < GRT_MAT_STRIDE * NP; i += blockDim.x) {
+      if (i < 2 * NP) lds[i] = S.prims[i];
       lds[2 * NP + i] = S.mats[i];
     }
+    if (oct)
+      for (int i = threadIdx.x; i < 8 * NP; i += blockDim.x)
+        octant_record(S.prims[2 * (i % NP)], S.prims[2 * (i % NP) + 1], i / NP, oct + (i / NP) * GRT_OCT_STRIDE(NP) + 8 * (i % NP));
     __syncthreads();
     T.tp = lds;
     T.tm = lds + 2 * NP;
+    T.oct = oct;
   } else {
     T.tp = S.prims;
     T.tm = S.mats;
@@ -118,12 +124,14 @@ template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NP == GRT_FAST_PRIMS && RELOAD && !PREFETCH && !QUEUE) ? 7 : 4)))
 void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
-  __shared__ float4 lds[NP > 0 ? 4 * NP : (NP == 0 && RELOAD ? 6 * GRT_LDS_PRIMS : 1)];
+  __shared__ float4 lds[NP > 0 ? (2 + GRT_MAT_STRIDE) * NP : (NP == 0 && RELOAD ? (4 + GRT_MAT_STRIDE) * GRT_LDS_PRIMS : 1)];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];  // [depth][thread]
   __shared__ float qacc[QUEUE ? 4 * 192 : 1];                  // wave-queue mode: [wave][pixel][rgb]
   __shared__ uint32_t qkey[QUEUE ? 4 * 64 : 1];
+  constexpr bool OCT = NP > 0 && RELOAD && !PREFETCH && !QUEUE;  // the production instance for <= 8 objects
+  __shared__ __attribute__((aligned(16))) float oct_tables[OCT ? 8 * GRT_OCT_STRIDE(NP > 0 ? NP : 1) : 4];
   SceneTables<NP> T;
-  load_tables<NP, NP == 0 && RELOAD>(S, lds, T);
+  load_tables<NP, NP == 0 && RELOAD>(S, lds, T, OCT && !J.no_octants ? oct_tables : nullptr);
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
@@ -169,12 +177,21 @@ void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
     result = mk3(Q.acc[3 * lane], Q.acc[3 * lane + 1], Q.acc[3 * lane + 2]);
   } else {
     const int pm_base = (lrow * S.W + x) * J.pm_batch - J.s_first;  // request slot of sample s: pm_base + s
+#ifdef GRT_COUNT_LEVELS
+    int levels = 0;
+#endif
     while (__any(alive)) {
+#ifdef GRT_COUNT_LEVELS
+      levels++;
+#endif
       if (alive)
         path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x, nullptr,
-                                           &J.pm, pm_base, T.ts, T.n_boxes);
+                                           &J.pm, pm_base, T.ts, T.n_boxes, T.oct);
     }
     result = L.acc;
+#ifdef GRT_COUNT_LEVELS
+    if (ray_count && lane == 0) atomicAdd(ray_count + 1, 64ull * (unsigned long long)levels);
+#endif
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
@@ -367,7 +384,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_trace_samples(KScene S, const int* __restrict__ pixel_xy, int n_pixels,
                                                        int samples, float* __restrict__ rgb,
                                                        int* __restrict__ n_rays_out) {
-  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+  __shared__ float4 lds[NP > 0 ? (2 + GRT_MAT_STRIDE) * NP : 1];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];
   SceneTables<NP> T;
   load_tables<NP>(S, lds, T);
@@ -504,11 +521,13 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
 // in-kernel, FP32 only, one checksum word per pixel = sum of (id+1).  A wave owns an 8x8
 // tile so its rays are coherent.  NP > 0: objects in LDS, unrolled loop (as k_pathtrace).
 template <int NP, bool PREFETCH = false>
-__global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum) {
-  __shared__ float4 lds[NP > 0 ? 4 * NP : 1];
+__global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum, int no_octants) {
+  __shared__ float4 lds[NP > 0 ? (2 + GRT_MAT_STRIDE) * NP : 1];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];
+  constexpr bool OCT = NP > 0 && !PREFETCH;
+  __shared__ __attribute__((aligned(16))) float oct_tables[OCT ? 8 * GRT_OCT_STRIDE(NP > 0 ? NP : 1) : 4];
   SceneTables<NP> T;
-  load_tables<NP>(S, lds, T);
+  load_tables<NP>(S, lds, T, OCT && !no_octants ? oct_tables : nullptr);
   const int lane = threadIdx.x & 63;
   const int tiles_x = (S.W + 7) >> 3, tiles_y = (S.H + 7) >> 3;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -530,6 +549,7 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
       id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256)
                                   : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256);
     else if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
+    else if (NP > 0 && T.oct) id = intersect_lds_oct<(NP > 0 ? NP : 1)>(T.oct + ray_octant(r.D) * GRT_OCT_STRIDE(NP > 0 ? NP : 1), S.box_mask, r, S.bias, t);
     else if (NP > 0) id = intersect_lds<NP, PREFETCH>(T.tp, S.box_mask, r, S.bias, t);
     else id = intersect32_t<false>(S, r, t);
     sum += (uint32_t)(id + 1);

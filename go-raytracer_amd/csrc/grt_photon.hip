@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos
         } else {
           f3 p, n;
           int m = surface32(S, id, r, t, p, n);
-          float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
+          float4 m0 = S.mats[GRT_MAT_STRIDE * m], m1 = S.mats[GRT_MAT_STRIDE * m + 1];
           int flags = __float_as_int(m1.w);
           f3 incident = r.D * rsq32(r.a);  // scene.go:371
           f3 f = mk3(m0.x, m0.y, m0.z);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos
             O = p, D = refl, power = power * f;
           } else if (flags & GRT_MAT_TRANSPARENT) {  // scene.go:403-412
             f3 dir;
-            if (!refract32(incident, n, rcp32(m0.w), grt_rng_draw(key, GRT_PDIM_HIT(depth, 2)), dir)) dir = reflect32(incident, n);
+            if (!refract32(incident, n, S.mats[GRT_MAT_STRIDE * m + 2], grt_rng_draw(key, GRT_PDIM_HIT(depth, 2)), dir)) dir = reflect32(incident, n);
             O = p, D = dir;
           } else {
             const float rrp = (f.x + f.y + f.z) * (1.0f / 3.0f);  // scene.go:388
