@@ -21,6 +21,8 @@ GRT_BAND_ROWS = 8
 GRT_ACCEL_AUTO = 0
 GRT_ACCEL_BVH = 1
 GRT_ACCEL_LINEAR = 2
+GRT_PMVIEW_IRRADIANCE = 0
+GRT_PMVIEW_FIRST_HIT = 1
 
 
 class Camera(C.Structure):
@@ -93,6 +95,8 @@ PROTOTYPES = {
     "grt_render_accum_pm": (C.c_int, [_vp, P(Opts), _vp, _vp, _vp, C.c_int32]),
     "grt_render_accum_pm_dev": (C.c_int, [_vp, P(Opts), _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_uint64, _vp, _vp]),
     "grt_render_pm_workspace_bytes": (C.c_uint64, [_vp, P(Opts), C.c_int32, C.c_int32, C.c_int32]),
+    "grt_render_pmview": (C.c_int, [_vp, P(Opts), _vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
+    "grt_render_accum_pmview": (C.c_int, [_vp, P(Opts), _vp, C.c_int32, _vp, C.c_int32]),
     "grt_rng_u01": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grt_last_ray_count": (C.c_uint64, []),
     "grt_last_kernel_ms": (C.c_double, []),

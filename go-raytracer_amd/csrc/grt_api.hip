@@ -639,6 +639,7 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->spp = samples;
   j->s_first = 0;
   j->pm.pos = j->pm.nrm = j->pm.w = nullptr;
+  j->pm.view = 0;
   j->pm_batch = 0;
   const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 64 = every level in lockstep
   j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 10;
@@ -662,14 +663,16 @@ GRT_API uint64_t grt_accum_workspace_bytes(const grt_scene* s, const grt_opts* o
 
 int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_shards, int sample_first, int samples,
                             float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream,
-                            float* pm_pos, float* pm_nrm, float* pm_w, int pm_batch) {
+                            float* pm_pos, float* pm_nrm, float* pm_w, int pm_batch, int pm_view) {
   if (!s || !d_rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_dev: NULL scene or output");
+  if (pm_view && !pm_pos) return grt_fail(GRT_EINVAL, "photon-map view without request arrays");
   if (sample_first < 0) return grt_fail(GRT_EINVAL, "first sample must not be negative (got %d)", sample_first);
   RenderJob j;
   int rc = make_job(s, o, shard, n_shards, samples, &j);
   if (rc) return rc;
   j.s_first = sample_first;
   j.pm.pos = pm_pos, j.pm.nrm = pm_nrm, j.pm.w = pm_w, j.pm_batch = pm_batch;
+  j.pm.view = pm_view;
   if (pm_pos && pm_batch < samples) return grt_fail(GRT_EINVAL, "photon-mapped render: batch %d < samples %d", pm_batch, samples);
   if (j.rows_local == 0) return GRT_OK;
   const uint64_t need = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
@@ -686,7 +689,11 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   // opts->flags bits 0-3: kernel variant for A/B timing (0 = default)
   const int variant = o ? (o->flags & 15) : 0;
   unsigned long long* rcnt = (unsigned long long*)d_ray_count;
-  if (s->use_bvh && variant == 5)  // every level in lockstep through path_advance (the state machine of the small scenes)
+  if (pm_view && s->use_bvh)  // photon-map view (a debug mode: the lockstep state machine over the hierarchy / the linear loop)
+    hipLaunchKernelGGL((k_pathtrace<-1, false, false, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  else if (pm_view)
+    hipLaunchKernelGGL((k_pathtrace<0, false, false, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+  else if (s->use_bvh && variant == 5)  // every level in lockstep through path_advance (the state machine of the small scenes)
     hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (s->use_bvh && variant == 6) {  // profiling build: d_ray_count holds 3 words (rays, inner nodes visited, objects tested)
     if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..2]: a NULL counter was passed");

@@ -374,6 +374,7 @@ struct PmOut {
   float* pos;  // [slots * 3], pre-filled with NaN = no request
   float* nrm;  // [slots * 3]
   float* w;    // [slots * 3]
+  int view;    // photon-map view kernels (VIEW): 1 = Scene.irradiance (scene.go:184-232), 2 = trace()'s debugging block (:261-271)
 };
 
 struct WaveQueue {
@@ -688,7 +689,7 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 
 // DIRECT: how the plain-diffuse branch finds its shadows: 0 linear loop (direct_light32), 1 the scene has
 // no plain-diffuse object (hierarchy scenes without one: the branch is compiled out), 2 hierarchy.
-template <bool QUEUE, int DIRECT = 0>
+template <bool QUEUE, int DIRECT = 0, bool VIEW = false>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t,
                         WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, int* bvh_stack = nullptr,
@@ -698,7 +699,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
 // and the intersect loop is unrolled over NP records; NP == 0: tp/tm are the HBM-resident
 // arrays of S and the loop runs over S.n_prims.  `alive` turns false when the lane has finished
 // sample s_end-1.  n_rays counts intersect() calls (scene.go:242).
-template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false, bool VIEW = false>
 GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                           uint32_t pix_key, int s_end, LaneState& L, bool& alive, int& n_rays, int* bvh_stack = nullptr,
                           WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, const float4* ts = nullptr,
@@ -725,12 +726,16 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
   else
     id = intersect32_t<false>(S, r, t);
   n_rays++;                                         // scene.go:242
-  path_shade<QUEUE, NP < 0 ? 2 : 0>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base, bvh_stack, 256, octq);
+  path_shade<QUEUE, NP < 0 ? 2 : 0, VIEW>(S, tp, tm, fx, fy, pix_key, s_end, L, alive, r, id, t, Q, pm, pm_base, bvh_stack, 256, octq);
 }
 
 // Everything of one trace() level after intersect(): Surface, material dispatch, the radiance a
 // terminating level carries, and the lane's next ray (same path, or the next sample's primary ray).
-template <bool QUEUE, int DIRECT>
+// VIEW: the photon-map view instead of trace() — Scene.irradiance (scene.go:184-232: metal and glass are followed,
+// every other surface, lights and Lambert walls included, shows IrradianceEst(p, n, 0, 100)) or, pm->view == 2,
+// trace()'s debugging block (scene.go:261-271: the estimate at the first hit).  The level leaves a gather request
+// with the path's throughput as its weight; nothing else carries radiance.
+template <bool QUEUE, int DIRECT, bool VIEW>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
                         const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride, const float* octq) {
@@ -743,17 +748,24 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   const int flags = __float_as_int(m1.w);
   const f3 color = mk3(m0.x, m0.y, m0.z);
   // material priority of scene.go:274-305: Normal, Emittance, Lambert, Reflectivity, Transparent, diffuse
-  const bool is_normal = hit & ((flags & GRT_MAT_NORMAL) != 0);
-  const bool is_emit = hit & !is_normal & (m1.z > 0.0f);
-  const bool rest = hit & !is_normal & !is_emit;
-  const bool is_lamb = rest & ((flags & GRT_MAT_LAMBERT) != 0);
-  const bool is_metal = rest & !is_lamb & (m1.x > 0.0f);
-  const bool is_glass = rest & !is_lamb & !is_metal & ((flags & GRT_MAT_TRANSPARENT) != 0);
-  const bool is_diff = rest & !is_lamb & !is_metal & !is_glass;
+  const bool is_normal = !VIEW & hit & ((flags & GRT_MAT_NORMAL) != 0);
+  const bool is_emit = !VIEW & hit & !is_normal & (m1.z > 0.0f);
+  const bool rest = VIEW ? (hit & (pm->view == 1)) : (hit & !is_normal & !is_emit);
+  const bool is_lamb = !VIEW & rest & ((flags & GRT_MAT_LAMBERT) != 0);
+  const bool is_metal = rest & !is_lamb & (m1.x > 0.0f);                                         // scene.go:207 / :287
+  const bool is_glass = rest & !is_lamb & !is_metal & ((flags & GRT_MAT_TRANSPARENT) != 0);     // scene.go:215 / :295
+  const bool is_diff = VIEW ? (hit & !is_metal & !is_glass) : (rest & !is_lamb & !is_metal & !is_glass);
   f3 rad = mk3(0.0f, 0.0f, 0.0f);
   if (is_emit) rad = color * m1.z;                                                              // scene.go:279
   if (is_normal) rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);      // scene.go:275
-  if (DIRECT != 1 && __builtin_expect(__any(is_diff), 0)) {
+  if (VIEW) {
+    if (is_diff) {                                   // scene.go:228 (k = 100) / :262,268 (k = 50): the gather runs after this launch
+      const size_t slot = 3 * (size_t)(pm_base + L.s);
+      pm->pos[slot] = p.x, pm->pos[slot + 1] = p.y, pm->pos[slot + 2] = p.z;
+      pm->nrm[slot] = n.x, pm->nrm[slot + 1] = n.y, pm->nrm[slot + 2] = n.z;
+      pm->w[slot] = L.thr.x, pm->w[slot + 1] = L.thr.y, pm->w[slot + 2] = L.thr.z;
+    }
+  } else if (DIRECT != 1 && __builtin_expect(__any(is_diff), 0)) {
     f3 direct = mk3(0.0f, 0.0f, 0.0f);
     if (DIRECT == 2) direct = direct_light_bvh(S, p, n, color, is_diff, bvh_stack, bvh_stride);  // wave-cooperative
     if (is_diff) {
@@ -823,7 +835,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
       L.thr = L.thr * color;
     } else if (is_metal) {
       L.D = dir;
-      L.thr = L.thr * (color * m1.x);
+      L.thr = L.thr * (VIEW ? color : color * m1.x);  // f.Times(...) (scene.go:213) | .Times(m.Color).Scale(m.Reflectivity) (:293)
     } else {                                        // scene.go:295-304; u1 is the roulette draw
       f3 d;
       if (!refract32(r.D, n, tm[GRT_MAT_STRIDE * m + 2], u1, d)) d = reflect32(r.D, n);

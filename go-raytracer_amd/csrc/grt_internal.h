@@ -74,6 +74,6 @@ const grt_scene_desc* grt_scene_desc_of(const grt_scene* s);
 // the photon-mapped trace() (all NULL / 0: off).
 int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_shards, int sample_first, int samples,
                             float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream,
-                            float* pm_pos, float* pm_nrm, float* pm_w, int pm_batch);
+                            float* pm_pos, float* pm_nrm, float* pm_w, int pm_batch, int pm_view = 0);
 int grt_pm_accumulate_internal(const float* frame, const float* qpos, const float* qw, const float* irr_g, const float* irr_c,
                                int batch, size_t n_pixels, float* total, int first_batch, void* stream);

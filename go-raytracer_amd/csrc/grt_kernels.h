@@ -118,7 +118,7 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T, float
 // in the same loop iteration, so every iteration of the wave-wide loop does one intersect()
 // for every lane that still has samples left — terminated paths never leave idle lanes
 // behind (the wave only drains when a lane runs out of samples; __any() is the ballot).
-template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false>
+template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false, bool VIEW = false>
 // The production instance for scenes of <= 8 objects is compiled for 7 waves per SIMD (72 VGPRs, 24 B of
 // scratch): 37.5 ms against 38.1 ms at 6 waves (76 VGPRs) for the C3 frame; 8 waves (64 VGPRs) the same.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NP == GRT_FAST_PRIMS && RELOAD && !PREFETCH && !QUEUE) ? 7 : 4)))
@@ -185,8 +185,8 @@ void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
       levels++;
 #endif
       if (alive)
-        path_advance<NP, RELOAD, PREFETCH>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x, nullptr,
-                                           &J.pm, pm_base, T.ts, T.n_boxes, T.oct);
+        path_advance<NP, RELOAD, PREFETCH, false, VIEW>(S, T.tp, T.tm, fx, fy, pix_key, s_end, L, alive, n_rays, bvh_stack + threadIdx.x,
+                                                        nullptr, &J.pm, pm_base, T.ts, T.n_boxes, T.oct);
     }
     result = L.acc;
 #ifdef GRT_COUNT_LEVELS
@@ -337,17 +337,17 @@ __global__ __launch_bounds__(256) void k_sum_chunks(const float* __restrict__ sl
 // Requests that were never written (NaN position) contribute nothing.  Fixed order: reproducible.
 __global__ __launch_bounds__(256) void k_pm_accumulate(const float* __restrict__ frame, const float* __restrict__ qpos,
                                                        const float* __restrict__ qw, const float* __restrict__ irr_g,
-                                                       const float* __restrict__ irr_c, int batch, size_t n_pixels,
-                                                       float* __restrict__ total, int first_batch) {
+                                                       const float* __restrict__ irr_c /* may be NULL: one map */, int batch,
+                                                       size_t n_pixels, float* __restrict__ total, int first_batch) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pixels) return;
   float r = frame[3 * i], g = frame[3 * i + 1], b = frame[3 * i + 2];
   for (int s = 0; s < batch; ++s) {
     const size_t q = 3 * (i * (size_t)batch + (size_t)s);
     if (qpos[q] == qpos[q]) {
-      r = fmaf(qw[q], irr_g[q] + irr_c[q], r);
-      g = fmaf(qw[q + 1], irr_g[q + 1] + irr_c[q + 1], g);
-      b = fmaf(qw[q + 2], irr_g[q + 2] + irr_c[q + 2], b);
+      r = fmaf(qw[q], irr_c ? irr_g[q] + irr_c[q] : irr_g[q], r);
+      g = fmaf(qw[q + 1], irr_c ? irr_g[q + 1] + irr_c[q + 1] : irr_g[q + 1], g);
+      b = fmaf(qw[q + 2], irr_c ? irr_g[q + 2] + irr_c[q + 2] : irr_g[q + 2], b);
     }
   }
   if (first_batch) total[3 * i] = r, total[3 * i + 1] = g, total[3 * i + 2] = b;

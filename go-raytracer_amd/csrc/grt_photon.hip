@@ -1254,6 +1254,7 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
 #define GRT_PM_BATCH 8
 #define GRT_PM_K 100          // scene.go:313,316
 #define GRT_PM_CAUSTIC_R 1.0f // scene.go:313
+#define GRT_PMVIEW_DEBUG_K 50 // scene.go:262,268
 
 static int pm_batch_of(int samples) { return std::min(samples, GRT_PM_BATCH); }
 
@@ -1266,10 +1267,12 @@ GRT_API uint64_t grt_render_pm_workspace_bytes(const grt_scene* s, const grt_opt
   return slabs + npix * 3 * sizeof(float) + 5 * npix * (uint64_t)B * 3 * sizeof(float) + 1024;
 }
 
-GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int32_t shard,
-                                    int32_t n_shards, int32_t samples, float* d_rgb_sum, void* d_workspace,
-                                    uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) try {
-  if (!s || !gmap || !cmap || !d_rgb_sum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: bad argument");
+// view == 0: trace() with both maps (scene.go:308-320).  view == 1 / 2: the photon-map view of ONE map (gmap; cmap
+// NULL): Scene.irradiance (scene.go:184-232, k = 100) / trace()'s debugging block (scene.go:261-271, k = 50).
+static int render_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int view, int32_t shard,
+                         int32_t n_shards, int32_t samples, float* d_rgb_sum, void* d_workspace, uint64_t workspace_bytes,
+                         uint64_t* d_ray_count, void* stream) {
+  if (!s || !gmap || (!cmap && !view) || !d_rgb_sum || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: bad argument");
   const uint64_t need = grt_render_pm_workspace_bytes(s, o, shard, n_shards, samples);
   if (!d_workspace || workspace_bytes < need)
     return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: workspace %llu bytes, need %llu", (unsigned long long)workspace_bytes,
@@ -1289,31 +1292,38 @@ GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_p
   for (int s0 = 0, first = 1; s0 < samples; s0 += B, first = 0) {
     const int b = std::min(B, samples - s0);
     GRT_HIP(hipMemsetAsync(qpos, 0xff, nq * 3 * sizeof(float), st));  // all bits set = NaN = no request
-    int rc = grt_render_dev_internal(s, o, shard, n_shards, s0, b, frame, base, slab_bytes, d_ray_count, stream, qpos, qnrm, qw, B);
+    int rc = grt_render_dev_internal(s, o, shard, n_shards, s0, b, frame, base, slab_bytes, d_ray_count, stream, qpos, qnrm, qw, B, view);
     if (rc) return rc;
-    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, GRT_PM_K, irr_g, nullptr, st);  // scene.go:316
+    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, irr_g, nullptr, st);  // scene.go:316 | :228 | :262,268
     if (rc) return rc;
-    rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st);  // scene.go:313
+    if (cmap) rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st);  // scene.go:313
     if (rc) return rc;
-    rc = grt_pm_accumulate_internal(frame, qpos, qw, irr_g, irr_c, B, npix, d_rgb_sum, first, stream);
+    rc = grt_pm_accumulate_internal(frame, qpos, qw, irr_g, cmap ? irr_c : nullptr, B, npix, d_rgb_sum, first, stream);
     if (rc) return rc;
   }
   return GRT_OK;
+}
+
+GRT_API int grt_render_accum_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int32_t shard,
+                                    int32_t n_shards, int32_t samples, float* d_rgb_sum, void* d_workspace,
+                                    uint64_t workspace_bytes, uint64_t* d_ray_count, void* stream) try {
+  if (!cmap) return grt_fail(GRT_EINVAL, "grt_render_accum_pm_dev: bad argument");
+  return render_pm_dev(s, o, gmap, cmap, 0, shard, n_shards, samples, d_rgb_sum, d_workspace, workspace_bytes, d_ray_count, stream);
 } catch (...) {
   return grt_fail_exception("grt_render_accum_pm_dev");
 }
 
 // Host-buffer form on one device: linear RGB sums [H*W*3] (rgb_sum) and / or tone-mapped B,G,R bytes (pixels).
 static int render_pm_host(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, const grt_pmap* cmap, int samples, float* rgb_sum,
-                          uint8_t* pixels, int pitch) {
-  if (!s || !gmap || !cmap || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_pm: bad argument");
+                          uint8_t* pixels, int pitch, int view = 0) {
+  if (!s || !gmap || (!cmap && !view) || samples <= 0) return grt_fail(GRT_EINVAL, "grt_render_pm: bad argument");
   if (o && o->n_devices > 1) return grt_fail(GRT_ELIMIT, "grt_render_pm: one device per call (shard with grt_render_accum_pm_dev)");
   DeviceGuard guard;
   int dev;
   int rc = pick_device(o, &dev);
-  if (!rc && (gmap->device != dev || cmap->device != dev))
+  if (!rc && (gmap->device != dev || (cmap && cmap->device != dev)))
     rc = grt_fail(GRT_EINVAL, "grt_render_pm: the photon maps live on devices %d and %d, the render was asked for device %d", gmap->device,
-                  cmap->device, dev);
+                  cmap ? cmap->device : gmap->device, dev);
   if (rc) return rc;
   const int W = grt_scene_desc_of(s)->width, H = grt_scene_desc_of(s)->height;
   const size_t nfl = (size_t)W * H * 3;
@@ -1325,7 +1335,7 @@ static int render_pm_host(grt_scene* s, const grt_opts* o, const grt_pmap* gmap,
   do {
     PTRY(hipMalloc(&d_sum, nfl * sizeof(float)));
     PTRY(hipMalloc(&d_ws, ws_bytes));
-    rc = grt_render_accum_pm_dev(s, o, gmap, cmap, 0, 1, samples, d_sum, d_ws, ws_bytes, nullptr, nullptr);
+    rc = render_pm_dev(s, o, gmap, cmap, view, 0, 1, samples, d_sum, d_ws, ws_bytes, nullptr, nullptr);
     if (rc) break;
     if (rgb_sum) PTRY(hipMemcpy(rgb_sum, d_sum, nfl * sizeof(float), hipMemcpyDeviceToHost));
     if (pixels) {
@@ -1356,4 +1366,33 @@ GRT_API int grt_render_accum_pm(grt_scene* s, const grt_opts* o, const grt_pmap*
   return render_pm_host(s, o, gmap, cmap, samples, rgb_sum, nullptr, 0);
 } catch (...) {
   return grt_fail_exception("grt_render_accum_pm");
+}
+
+// ---- photon-map view ------------------------------------------------------
+// Scene.irradiance (scene.go:184-232) has no caller upstream; it is what Render shows when it stands in for
+// trace() at scene.go:96: mirrors and glass are followed (weights f, 1), every other surface shows
+// pmap.IrradianceEst(p, n, 0, 100).  GRT_PMVIEW_FIRST_HIT is the debugging block inside trace()
+// (scene.go:261-271): IrradianceEst(p, n, 0, 50) at the first hit, whatever its material.
+static int pmview_mode(int32_t mode, int* view) {
+  if (mode != GRT_PMVIEW_IRRADIANCE && mode != GRT_PMVIEW_FIRST_HIT) return grt_fail(GRT_EINVAL, "grt_render_pmview: unknown mode %d", mode);
+  *view = mode == GRT_PMVIEW_IRRADIANCE ? 1 : 2;
+  return GRT_OK;
+}
+GRT_API int grt_render_pmview(grt_scene* s, const grt_opts* o, const grt_pmap* pmap, int32_t mode, uint8_t* pixels, int32_t pitch,
+                              int32_t samples) try {
+  if (!pixels || !s || pitch / grt_scene_desc_of(s)->width < 3) return grt_fail(GRT_EINVAL, "grt_render_pmview: NULL pixels or pitch too small");
+  int view;
+  const int rc = pmview_mode(mode, &view);
+  return rc ? rc : render_pm_host(s, o, pmap, nullptr, samples, nullptr, pixels, pitch, view);
+} catch (...) {
+  return grt_fail_exception("grt_render_pmview");
+}
+GRT_API int grt_render_accum_pmview(grt_scene* s, const grt_opts* o, const grt_pmap* pmap, int32_t mode, float* rgb_sum,
+                                    int32_t samples) try {
+  if (!rgb_sum) return grt_fail(GRT_EINVAL, "grt_render_accum_pmview: NULL output");
+  int view;
+  const int rc = pmview_mode(mode, &view);
+  return rc ? rc : render_pm_host(s, o, pmap, nullptr, samples, rgb_sum, nullptr, 0, view);
+} catch (...) {
+  return grt_fail_exception("grt_render_accum_pmview");
 }

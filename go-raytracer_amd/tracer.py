@@ -284,6 +284,21 @@ class Scene:
                                             _ptr(out), samples))
         return out
 
+    def RenderAccumPhotonView(self, pmap, samples, seed=None, mode=_capi.GRT_PMVIEW_IRRADIANCE):
+        """Render through Scene.irradiance (scene.go:184-232) or, mode GRT_PMVIEW_FIRST_HIT, trace()'s debugging
+        block (scene.go:261-271): linear RGB sums [H, W, 3]."""
+        out = np.empty((self.H, self.W, 3), np.float32)
+        o = self.opts(seed)
+        check(self._lib.grt_render_accum_pmview(self.handle, C.byref(o), pmap.handle, mode, _ptr(out), samples))
+        return out
+
+    def RenderPhotonView(self, pmap, pixels, pitch, samples, seed=None, mode=_capi.GRT_PMVIEW_IRRADIANCE):
+        buf = np.frombuffer(pixels, dtype=np.uint8) if not isinstance(pixels, np.ndarray) else pixels
+        if buf.size < self.H * pitch:
+            raise ValueError("pixels buffer smaller than H*pitch")
+        o = self.opts(seed)
+        check(self._lib.grt_render_pmview(self.handle, C.byref(o), pmap.handle, mode, _ptr(buf), pitch, samples))
+
     def TraceSamples(self, pixel_xy, samples, seed=None):
         xy = np.ascontiguousarray(pixel_xy, np.int32).reshape(-1, 2)
         rgb = np.empty((xy.shape[0], samples, 3), np.float32)

@@ -284,6 +284,21 @@ int grt_render_accum_pm_dev(grt_scene* scene, const grt_opts* opts, const grt_pm
 uint64_t grt_render_pm_workspace_bytes(const grt_scene* scene, const grt_opts* opts, int32_t shard,
                                        int32_t n_shards, int32_t samples);
 
+/* ---- photon-map view ------------------------------------------------------------------- */
+
+/* Scene.irradiance (scene.go:184-232; no caller in the reference) as a render mode: Scene.Render with
+ * irradiance(pmap, Cam.Ray(u,v), 1, rnd) where scene.go:96 calls trace().  Metal (f * irradiance of the
+ * reflected ray when reflected.Dot(n) > 0, scene.go:207-214) and glass (scene.go:215-224) are followed up to
+ * maxDepth; every other surface — lights and Lambert walls included — shows pmap.IrradianceEst(p, n, 0, 100)
+ * (scene.go:228).  GRT_PMVIEW_FIRST_HIT is the debugging block of trace() (scene.go:261-271):
+ * IrradianceEst(p, n, 0, 50) at the first hit.  Buffers as grt_render / grt_render_accum; one device per call. */
+#define GRT_PMVIEW_IRRADIANCE 0
+#define GRT_PMVIEW_FIRST_HIT 1
+int grt_render_pmview(grt_scene* scene, const grt_opts* opts, const grt_pmap* pmap, int32_t mode, uint8_t* pixels,
+                      int32_t pitch, int32_t samples);
+int grt_render_accum_pmview(grt_scene* scene, const grt_opts* opts, const grt_pmap* pmap, int32_t mode, float* rgb_sum,
+                            int32_t samples);
+
 /* ---- misc ----------------------------------------------------------------------------- */
 
 /* Uniform in [0,1) with 24 random bits: draw `dim` of sample `sample` of pixel `pixel`

@@ -30,6 +30,7 @@ PROTOTYPES = {
                                     P(_capi.MaterialRec), C.c_int32, P(_vp)]),
     "grto_scene_destroy": (None, [_vp]),
     "grto_scene_set_pmaps": (None, [_vp, _vp, _vp]),
+    "grto_scene_set_view": (None, [_vp, _vp, C.c_int32]),
     "grto_intersect": (C.c_int, [_vp, _d3, _d3, P(C.c_double)]),
     "grto_reflect": (None, [_d3, _d3, _d3]),
     "grto_refract": (C.c_int, [_d3, _d3, C.c_double, C.c_double, _d3]),
@@ -104,6 +105,12 @@ class OracleScene:
         self._pmaps = (global_map, caustic_map)  # keep them alive
         self.lib.grto_scene_set_pmaps(self.handle, global_map.handle if global_map else None,
                                       caustic_map.handle if caustic_map else None)
+
+    def SetView(self, pmap, mode):
+        """Photon-map view: mode 1 = Render through irradiance() (scene.go:184-232), 2 = trace()'s debugging block
+        (scene.go:261-271, k = 50); pmap None switches it off."""
+        self._view = pmap
+        self.lib.grto_scene_set_view(self.handle, pmap.handle if pmap else None, mode)
 
     def Render(self, pixels, pitch, samples, seed=1, nthreads=0):
         rc = self.lib.grto_render(self.handle, seed, _ptr(pixels), pitch, samples, nthreads)

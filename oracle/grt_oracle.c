@@ -244,6 +244,11 @@ struct grto_scene {
    * stays commented out as in the reference (scene.go:308-320) */
   const struct grto_pmap* global_pmap;
   const struct grto_pmap* caustic_pmap;
+  /* photon-map view (no caller in the reference): 0 off; 1 = Render with irradiance() (scene.go:184-232) in
+   * place of trace(); 2 = trace() with its debugging block enabled (scene.go:261-271): IrradianceEst(p, n, 0, 50)
+   * of view_pmap at the first hit */
+  int view;
+  const struct grto_pmap* view_pmap;
 };
 typedef struct grto_scene grto_scene;
 static void irradiance_est(const struct grto_pmap* m, const double* pos, const double* nrm, double radius, int k, int brute,
@@ -252,6 +257,11 @@ static void irradiance_est(const struct grto_pmap* m, const double* pos, const d
 GRTO_API void grto_scene_set_pmaps(grto_scene* s, const struct grto_pmap* global_map, const struct grto_pmap* caustic_map) {
   s->global_pmap = global_map;
   s->caustic_pmap = caustic_map;
+}
+
+GRTO_API void grto_scene_set_view(grto_scene* s, const struct grto_pmap* map, int32_t mode) {
+  s->view = map ? mode : 0;
+  s->view_pmap = map;
 }
 
 GRTO_API int grto_scene_create(const grt_scene_desc* desc, const grt_prim* prims, int32_t n_prims,
@@ -376,6 +386,46 @@ typedef struct {
   int n_rays; /* intersect() calls (scene.go:242), shadow loops not counted */
 } pathctx;
 
+/* Scene.irradiance (scene.go:184-232; dead code upstream): direct visualisation of a photon map through
+ * specular chains.  Note what it does NOT test: Normal, Emittance and Lambert materials are "diffuse" here. */
+static v3 irradiance(const grto_scene* s, const struct grto_pmap* pmap, ray r, int depth, pathctx* px) {
+  v3 black = V(0, 0, 0);
+  if (depth >= s->d.max_depth) return black; /* :187-189 */
+  double tNear;
+  px->n_rays++;
+  int id = intersect(s, r, NULL, s->n_prims, &tNear); /* :191 */
+  if (id < 0) return black;
+  v3 incident = v_unit(r.dir); /* :197 */
+  v3 p = ray_at(r, tNear);
+  const grt_prim* o = &s->prims[id];
+  v3 n = prim_surface(o, p);
+  const grt_material* m = &s->mats[o->material];
+  v3 f = from3(m->color); /* :205 */
+  if (m->reflectivity > 0) { /* :207-214 */
+    v3 refl = reflect(incident, n);
+    v3 fz = sample_hemisphere_normal(n, rng_draw(px->path_key, DIM_HIT(depth, 0)), rng_draw(px->path_key, DIM_HIT(depth, 1)));
+    refl = v_plus(refl, v_scale(fz, m->roughness));
+    if (v_dot(refl, n) > 0) {
+      ray r2 = {p, refl};
+      return v_times(f, irradiance(s, pmap, r2, depth + 1, px));
+    }
+  } else if (m->transparent) { /* :215-224 */
+    double refrRatio = 1.0 / m->refr_index;
+    v3 dir;
+    int ok = refract(incident, n, refrRatio, rng_draw(px->path_key, DIM_HIT(depth, 0)), &dir);
+    if (!ok) dir = reflect(incident, n);
+    ray r2 = {p, dir};
+    return irradiance(s, pmap, r2, depth + 1, px);
+  } else { /* :225-230 */
+    double pp[3], nn[3], e[3];
+    to3(pp, p);
+    to3(nn, n);
+    irradiance_est(pmap, pp, nn, 0, 100, 0, e);
+    return from3(e);
+  }
+  return black;
+}
+
 static v3 trace(const grto_scene* s, ray r, int depth, pathctx* px) {
   v3 black = V(0, 0, 0);
   if (depth >= s->d.max_depth) return black; /* scene.go:238-240 */
@@ -391,6 +441,13 @@ static v3 trace(const grto_scene* s, ray r, int depth, pathctx* px) {
   const grt_material* m = &s->mats[o->material];
   v3 mc = from3(m->color);
   /* orientedN (:256-259) is computed and never used in trace */
+  if (s->view == 2) { /* the debugging block, :261-271 */
+    double pp[3], nn[3], e[3];
+    to3(pp, p);
+    to3(nn, n);
+    irradiance_est(s->view_pmap, pp, nn, 0, 50, 0, e);
+    return v_plus(result, from3(e));
+  }
   if (m->normal) /* :274-276 */
     return v_scale(V(n.x + 0.5, n.y + 0.5, n.z + 0.5), 0.5);
   if (m->emittance > 0) { /* :278-279 */
@@ -459,7 +516,7 @@ static v3 trace_sample(const grto_scene* s, uint32_t seed32, int x, int y, uint3
   double u = ((double)x + rng_draw(px.path_key, DIM_JITTER_U)) / (double)s->d.width;
   double v = ((double)y + rng_draw(px.path_key, DIM_JITTER_V)) / (double)s->d.height;
   ray r = camera_ray(&s->d.cam, u, v);
-  v3 c = trace(s, r, 1, &px);
+  v3 c = s->view == 1 ? irradiance(s, s->view_pmap, r, 1, &px) : trace(s, r, 1, &px);
   if (n_rays) *n_rays = px.n_rays;
   return c;
 }

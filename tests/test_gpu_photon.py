@@ -242,3 +242,42 @@ def test_load_dev_on_a_second_gpu(pkg):
     for a, b in zip(m.read(), ref.read()):
         assert (a == b).all()
     assert torch.cuda.current_device() == 0
+
+
+@pytest.mark.parametrize("accel", ["auto", "bvh"])
+def test_photon_map_view_matches_oracle(pkg, ob, accel):
+    """Scene.irradiance (scene.go:184-232, dead code upstream) as a render mode, and the debugging
+    block of trace() (scene.go:261-271).  Mirror and glass are followed, every other surface — the light and a
+    Lambert box included — shows IrradianceEst(p, n, 0, 100); the debug view shows IrradianceEst(p, n, 0, 50) at
+    the first hit.  Against the oracle's recursive restatement with the same photons and RNG streams."""
+    C, T = pkg._capi, pkg.tracer
+    W, H, S = 64, 48, 10                                   # one full batch of 8 + a partial one
+    objs = pkg.scenes.cornell_objects("cornell8d") + [T.NewAABB((60, 0.1, 300), (160, 120, 400), T.LambertMaterial((0.7, 0.6, 0.2))),
+                                                     T.NewSphere((300, 60, 120), 60, T.MetalicMaterial((0.9, 0.6, 0.3), 0.8, 0.3))]
+    scene = T.Scene(W, H, pkg.scenes.cornell_camera(W / H), objs, accel=C.GRT_ACCEL_BVH if accel == "bvh" else C.GRT_ACCEL_AUTO)
+    gmap = T.PhotonMap(30000).build(scene, caustics=False, seed=1)
+    p, w, t = gmap.read()
+    omap = ob.OraclePhotonMap.load(p.astype(np.float64), w.astype(np.float64), t)
+    ref = ob.OracleScene(scene.flat)
+    for mode, omode in ((C.GRT_PMVIEW_IRRADIANCE, 1), (C.GRT_PMVIEW_FIRST_HIT, 2)):
+        a = scene.RenderAccumPhotonView(gmap, S, seed=4, mode=mode).astype(np.float64) / S
+        ref.SetView(omap, omode)
+        b = ref.RenderAccum(S, seed=4) / S
+        ref.SetView(None, 0)
+        assert a.max() > 0 and np.isfinite(a).all()
+        close = np.isclose(a, b, rtol=5e-3, atol=1e-4 * b.max()).all(-1)
+        print(f"{accel} view mode {mode}: pixels within 5e-3 of the oracle {close.mean():.4f}, mean {a.mean((0, 1))} vs {b.mean((0, 1))}")
+        assert close.mean() > 0.97                          # rest: FP32 path divergence at silhouettes, k-th place swaps
+        assert np.allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=1e-2)
+    # the view differs from trace(): the light itself shows the photon estimate (scene.go:225-230 has no Emittance case)
+    first = scene.RenderAccumPhotonView(gmap, 2, seed=4, mode=C.GRT_PMVIEW_FIRST_HIT)
+    ids, _, _, _ = scene.PrimaryHits()
+    assert (first[ids < 0] == 0).all()                      # a miss is black (scene.go:193-195)
+    px = np.zeros(H * W * 4, np.uint8)
+    scene.RenderPhotonView(gmap, px, 4 * W, S, seed=4)
+    a = scene.RenderAccumPhotonView(gmap, S, seed=4).astype(np.float64) / S
+    img = px.reshape(H, W, 4)[..., 2::-1].astype(np.float64)
+    want = np.floor(255.99 * np.minimum(1.0, np.sqrt(a)))
+    assert (np.abs(img - want) <= 1).mean() > 0.999
+    with pytest.raises(C.GrtError, match="unknown mode"):
+        scene.RenderAccumPhotonView(gmap, 1, seed=1, mode=7)

@@ -104,3 +104,38 @@ def test_map_photons_semantics(pkg, ob):
     cpos, cpw, _ = c.read()
     first_white = 1 * 0.73 / (1 - 0.73) * 1000 / 500  # refracted twice (power unchanged), absorbed on the white floor
     assert np.isclose(cpw, first_white, rtol=1e-12).all(1).mean() > 0.5
+
+
+def test_irradiance_view_is_the_gather_at_the_first_non_specular_hit(pkg, ob):
+    """Oracle wiring of Scene.irradiance (scene.go:184-232) and of trace()'s debugging block (:261-271): on a scene
+    without mirrors or glass, one sample per pixel shows IrradianceEst(p, n, 0, k) at the primary hit — lights and
+    Lambert walls included, k = 100 for irradiance(), 50 for the debugging block; a miss is black."""
+    W, H = 24, 18
+    objs = pkg.scenes.cornell_objects("cornell8d")[:6] + pkg.scenes.cornell_objects()[3:4]   # a Lambert copy of the back wall
+    flat = pkg.tracer.flatten(W, H, pkg.scenes.cornell_camera(W / H), objs)
+    s = ob.OracleScene(flat)
+    rs = np.random.RandomState(3)
+    n = 4000
+    pos = rs.uniform(0, 555, (n, 3))
+    pos[: n // 2, 1] = 0.1                                                   # half of them on the floor
+    power = rs.uniform(0.0, 0.02, (n, 3))
+    tp = rs.randint(0, 256, (n, 2)).astype(np.uint8)
+    m = ob.OraclePhotonMap.load(pos, power, tp)
+    ids, t, nrm = s.PrimaryHits(1, 7)                                        # the jitter of sample 0
+    c = flat[0].cam
+    ys, xs = np.mgrid[0:H, 0:W]
+    ju = np.vectorize(lambda x, y: ob.load().grto_rng_u01(7, y * W + x, 0, 0))(xs, ys)
+    jv = np.vectorize(lambda x, y: ob.load().grto_rng_u01(7, y * W + x, 0, 1))(xs, ys)
+    u, v = (xs + ju) / W, (ys + jv) / H
+    D = (np.array(c.lower_left)[None, None] + np.array(c.horizontal)[None, None] * u[..., None]
+         + np.array(c.vertical)[None, None] * v[..., None] - np.array(c.origin)[None, None])
+    P = np.array(c.origin)[None, None] + D * t[..., None]
+    hit = ids >= 0
+    assert hit.any() and (~hit).any() and (ids == 0).any()                   # the light is among the hits
+    for mode, k in ((1, 100), (2, 50)):
+        want = np.zeros((H, W, 3))
+        want[hit] = m.gather(P[hit], nrm[hit], 0.0, k)
+        s.SetView(m, mode)
+        got = s.RenderAccum(1, seed=7)
+        s.SetView(None, 0)
+        assert np.allclose(got, want, rtol=1e-12, atol=0) and got[hit].max() > 0
