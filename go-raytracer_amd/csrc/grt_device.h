@@ -351,7 +351,7 @@ struct LaneState {
   f3 O, D;       // current ray; D is unit length (primary rays are normalised at birth: only
                  // p = O + tD and D/|D| are observable in trace(), scene.go:253-254)
   f3 thr, acc;   // path throughput, sum of finished paths' radiance (scene.go:96)
-  uint32_t pkey; // RNG key of the current path
+  grt_key pkey;  // RNG key of the current path (two words, grt_rng.h)
   int depth;     // scene.go:237 `depth` of the ray in flight (1 = primary)
   int s;         // sample index of the current path
   int pix;       // wave-queue mode: which of the tile's 64 pixels the current path belongs to
@@ -819,7 +819,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
     if (term) {                                     // next sample of this pixel (scene.go:92)
       L.s++;
       alive = L.s < s_end;
-      L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
+      L.pkey = grt_rng_next_path_key(pix_key, (uint32_t)L.s, L.pkey);
       L.depth = 0;
       L.thr = mk3(1.0f, 1.0f, 1.0f);
     }

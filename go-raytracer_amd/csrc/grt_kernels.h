@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   const int y = (int)(j / (size_t)S.W), x = (int)(j - (size_t)y * (size_t)S.W);
   uint32_t b0 = 1u << 23, b1 = 1u << 23;  // 0.5 * 2^24
   if (jitter_mode == 1) {
-    uint32_t pk = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)j), 0);
+    const grt_key pk = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)j), 0);
     b0 = grt_rng_bits24(pk, GRT_DIM_JITTER_U);
     b1 = grt_rng_bits24(pk, GRT_DIM_JITTER_V);
   }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
   uint32_t sum = 0;
   for (int s = 0; s < samples; ++s) {
     if (NP > 0) asm volatile("" ::: "memory");  // re-read the objects from LDS each ray (see path_advance)
-    uint32_t pk = grt_rng_path_key(pix_key, (uint32_t)s);
+    const grt_key pk = grt_rng_path_key(pix_key, (uint32_t)s);
     f3 O, D;
     make_primary(S, x, y, grt_rng_draw(pk, GRT_DIM_JITTER_U), grt_rng_draw(pk, GRT_DIM_JITTER_V), O, D);
     Ray32 r;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n_emit;
   const unsigned long long e = first + (unsigned long long)(valid ? i : 0);
-  const uint32_t key = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)e),
+  const grt_key key = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)e),
                                         (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
   f3 O = mk3(light_pos.x, light_pos.y, light_pos.z);  // l.Pos(), scene.go:149
   f3 D = sample_hemi32(mk3(0.0f, -1.0f, 0.0f), grt_rng_draw(key, GRT_PDIM_EMIT_U), grt_rng_draw(key, GRT_PDIM_EMIT_V));

@@ -6,9 +6,16 @@
 // start any sample of any pixel and the image does not depend on how the work is sharded.
 //
 //   mix32       2-multiply avalanche hash ("lowbias32"), a bijection on 32 bits
-//   pixel_key   once per pixel  (per lane, amortised over all samples of the pixel)
-//   path_key    once per path
-//   draw        one mix32 per uniform; 24 random bits -> exactly representable in f32 and f64
+//   pixel_key   once per pixel  (per lane, amortised over all samples of the pixel); a bijection of the pixel
+//               index for a given seed
+//   path_key    once per path: TWO words, a = mix32(pixel_key + sample * C2 + ..), b = pixel_key + sample * C4
+//               + .. (not hashed: it only has to tell apart the rare paths whose first words collide, and one
+//               add per path keeps it current).  C2 - C4 is odd, so two (pixel, sample) pairs that agree in both
+//               words agree in pixel_key + sample * C2 and in pixel_key + sample * C4, hence in sample and in
+//               pixel: no two paths of a frame share a key.  (With one 32-bit word, as in round 1, a third of the 2*10^9
+//               paths of a 1080p x 1000 spp frame shared their whole stream with a path of another pixel.)
+//   draw        one mix32 per uniform with word b folded in between its two multiply rounds (one three-input
+//               xor, no extra instruction); 24 random bits -> exactly representable in f32 and f64
 #pragma once
 #include <stdint.h>
 
@@ -32,16 +39,36 @@ GRT_HD uint32_t grt_rng_seed32(uint64_t seed) {
 GRT_HD uint32_t grt_rng_pixel_key(uint32_t seed32, uint32_t pixel) {
   return grt_mix32(seed32 ^ (pixel * 0x9E3779B1U));
 }
-GRT_HD uint32_t grt_rng_path_key(uint32_t pixel_key, uint32_t sample) {
-  return grt_mix32(pixel_key + sample * 0x85EBCA77U + 0xC2B2AE3DU);
+typedef struct {
+  uint32_t a, b;
+} grt_key;
+#define GRT_RNG_C4 0x27D4EB2EU  // 0x85EBCA77 - 0x27D4EB2E is odd
+GRT_HD grt_key grt_rng_path_key(uint32_t pixel_key, uint32_t sample) {
+  grt_key k;
+  k.a = grt_mix32(pixel_key + sample * 0x85EBCA77U + 0xC2B2AE3DU);
+  k.b = pixel_key + sample * GRT_RNG_C4 + 0x165667B1U;
+  return k;
 }
-GRT_HD uint32_t grt_rng_bits24(uint32_t path_key, uint32_t dim) {
-  return grt_mix32(path_key + (dim + 1U) * 0x9E3779B9U) >> 8;
+// The key of the NEXT sample of the same pixel from the current one: word b by one add.
+GRT_HD grt_key grt_rng_next_path_key(uint32_t pixel_key, uint32_t next_sample, grt_key cur) {
+  grt_key k;
+  k.a = grt_mix32(pixel_key + next_sample * 0x85EBCA77U + 0xC2B2AE3DU);
+  k.b = cur.b + GRT_RNG_C4;
+  return k;
 }
-GRT_HD float grt_rng_draw(uint32_t path_key, uint32_t dim) {
+GRT_HD uint32_t grt_rng_bits24(grt_key key, uint32_t dim) {
+  uint32_t x = key.a + (dim + 1U) * 0x9E3779B9U;
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= (x >> 15) ^ key.b;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x >> 8;
+}
+GRT_HD float grt_rng_draw(grt_key path_key, uint32_t dim) {
   return (float)grt_rng_bits24(path_key, dim) * (1.0f / 16777216.0f);
 }
-GRT_HD double grt_rng_draw64(uint32_t path_key, uint32_t dim) {
+GRT_HD double grt_rng_draw64(grt_key path_key, uint32_t dim) {
   return (double)grt_rng_bits24(path_key, dim) * (1.0 / 16777216.0);
 }
 

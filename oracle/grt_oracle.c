@@ -113,11 +113,23 @@ static inline uint32_t rng_seed32(uint64_t seed) {
 static inline uint32_t rng_pixel_key(uint32_t seed32, uint32_t pixel) {
   return mix32(seed32 ^ (pixel * 0x9E3779B1U));
 }
-static inline uint32_t rng_path_key(uint32_t pixel_key, uint32_t sample) {
-  return mix32(pixel_key + sample * 0x85EBCA77U + 0xC2B2AE3DU);
+/* Two-word path key: no two (pixel, sample) pairs of a frame share it (csrc/grt_rng.h). */
+typedef struct {
+  uint32_t a, b;
+} rng_key;
+static inline rng_key rng_path_key(uint32_t pixel_key, uint32_t sample) {
+  rng_key k;
+  k.a = mix32(pixel_key + sample * 0x85EBCA77U + 0xC2B2AE3DU);
+  k.b = pixel_key + sample * 0x27D4EB2EU + 0x165667B1U;
+  return k;
 }
-static inline double rng_draw(uint32_t path_key, uint32_t dim) {
-  uint32_t h = mix32(path_key + (dim + 1U) * 0x9E3779B9U);
+static inline double rng_draw(rng_key path_key, uint32_t dim) {
+  uint32_t h = path_key.a + (dim + 1U) * 0x9E3779B9U;
+  h ^= h >> 16;
+  h *= 0x7feb352dU;
+  h ^= (h >> 15) ^ path_key.b;
+  h *= 0x846ca68bU;
+  h ^= h >> 16;
   return (double)(h >> 8) * (1.0 / 16777216.0);
 }
 GRTO_API double grto_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
@@ -382,7 +394,7 @@ GRTO_API void grto_sample_hemisphere_normal(const double* n, double u1, double u
  * Scene.trace (scene.go:237-349), recursive as in the reference.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
-  uint32_t path_key;
+  rng_key path_key;
   int n_rays; /* intersect() calls (scene.go:242), shadow loops not counted */
 } pathctx;
 
@@ -643,7 +655,7 @@ GRTO_API int grto_primary_hits(const grto_scene* s, uint64_t seed, int32_t jitte
     for (int x = 0; x < W; x++) {
       double ju = 0.5, jv = 0.5;
       if (jitter_mode == GRT_JITTER_RNG) {
-        uint32_t pk = rng_path_key(rng_pixel_key(seed32, (uint32_t)y * (uint32_t)W + (uint32_t)x), 0);
+        rng_key pk = rng_path_key(rng_pixel_key(seed32, (uint32_t)y * (uint32_t)W + (uint32_t)x), 0);
         ju = rng_draw(pk, DIM_JITTER_U);
         jv = rng_draw(pk, DIM_JITTER_V);
       }

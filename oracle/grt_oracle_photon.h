@@ -97,7 +97,7 @@ static void pmap_store(grto_pmap* m, v3 power, v3 pos, v3 dir) { /* photon_mappi
 }
 
 /* tracePhotons (scene.go:354-424), iterative: every branch makes at most one recursive call. */
-static void trace_photon(const grto_scene* s, ray r, v3 power, grto_pmap* m, int caustics, uint32_t key) {
+static void trace_photon(const grto_scene* s, ray r, v3 power, grto_pmap* m, int caustics, rng_key key) {
   for (int depth = 1; depth < s->d.max_depth; depth++) { /* :355 */
     double tNear;
     if (caustics && depth == 1) { /* :359-363 */
@@ -295,7 +295,7 @@ GRTO_API int grto_photon_build(const grto_scene* s, uint64_t seed, int32_t max_p
     v3 pos = prim_pos(l), nl = V(0, -1, 0); /* scene.go:149-150 */
     long target = (long)m->max * (long)(int)(s->light_area / area);
     while (m->n < target && m->n < m->max && e < max_emit) { /* scene.go:152 / :157 */
-      uint32_t key = rng_path_key(rng_pixel_key(seed32, (uint32_t)e), (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
+      rng_key key = rng_path_key(rng_pixel_key(seed32, (uint32_t)e), (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
       ray rp = {pos, sample_hemisphere_normal(nl, rng_draw(key, PDIM_EMIT_U), rng_draw(key, PDIM_EMIT_V))};
       trace_photon(s, rp, power0, m, caustics, key);
       e++;
