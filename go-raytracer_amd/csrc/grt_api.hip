@@ -173,6 +173,14 @@ GRT_API void grt_scene_destroy(grt_scene* s) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
     free_device_scene(kv.second);
   }
+  for (auto& kv : s->rcache) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    HostRenderCache& c = kv.second;
+    (void)hipFree(c.d_sum), (void)hipFree(c.d_ws), (void)hipFree(c.d_rays), (void)hipFree(c.d_bgr);
+    (void)hipHostFree(c.h_sum), (void)hipHostFree(c.h_bgr);
+    if (c.e0) (void)hipEventDestroy(c.e0);
+    if (c.e1) (void)hipEventDestroy(c.e1);
+  }
   if (have) (void)hipSetDevice(cur);
   delete s;
 }
@@ -816,7 +824,7 @@ GRT_API int grt_tonemap_dev(const float* d_rgb_sum, int32_t width, int32_t rows,
   const size_t n = (size_t)width * rows;
   const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_tonemap, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_rgb_sum, width, rows,
-                     1.0f / (float)samples, d_bgrx, pitch, bpp);
+                     1.0f / (float)samples, d_bgrx, pitch, bpp, 0, 1);
   GRT_HIP(hipGetLastError());
   return GRT_OK;
 } catch (...) {
@@ -831,9 +839,33 @@ struct ShardResult {
   float ms = 0.0f;
 };
 
-// Renders one shard on `device` and scatters its rows into the caller's host buffers.
+// Grows a cached buffer (device or pinned host) to `need` bytes; the old contents are not kept.
+template <class T>
+static hipError_t grow_device(T** p, size_t* cap, size_t need) {
+  if (need <= *cap) return hipSuccess;
+  (void)hipFree(*p);
+  *p = nullptr, *cap = 0;
+  const hipError_t e = hipMalloc((void**)p, need);
+  if (e == hipSuccess) *cap = need;
+  return e;
+}
+template <class T>
+static hipError_t grow_pinned(T** p, size_t* cap, size_t need) {
+  if (need <= *cap) return hipSuccess;
+  (void)hipHostFree(*p);
+  *p = nullptr, *cap = 0;
+  const hipError_t e = hipHostMalloc((void**)p, need, hipHostMallocDefault);
+  if (e == hipSuccess) *cap = need;
+  return e;
+}
+
+// Renders one shard on `device` into the caller's host buffers (the collector of scene.go:123-132).  Device
+// buffers, pinned staging and events live in the scene's HostRenderCache: after the first frame a call allocates
+// nothing.  pixels_mapped != NULL: the caller's pixel buffer is registered with HIP (render_host) and this is its
+// device address — k_tonemap stores B,G,R straight into the caller's memory, rows at their frame positions, bytes
+// beyond the third of a pixel never written (scene.go:71-73): no staging copy, no host scatter.
 static void render_shard_host(grt_scene* s, const grt_opts* o, int device, int shard, int n_shards, int samples,
-                              float* rgb_sum, uint8_t* pixels, int pitch, ShardResult* res) {
+                              float* rgb_sum, uint8_t* pixels, uint8_t* pixels_mapped, int pitch, ShardResult* res) {
   auto fail = [&](int rc) {
     res->rc = rc;
     res->err = g_err;
@@ -844,68 +876,72 @@ static void render_shard_host(grt_scene* s, const grt_opts* o, int device, int s
   if (rows == 0) return;
   const size_t nfl = (size_t)rows * W * 3;
   const uint64_t ws_bytes = grt_accum_workspace_bytes(s, o, shard, n_shards, samples);
-  float* d_sum = nullptr;
-  void* d_ws = nullptr;
-  uint64_t* d_rays = nullptr;
-  uint8_t* d_bgr = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HostRenderCache* cp;
+  {
+    std::lock_guard<std::mutex> lock(s->mu);
+    cp = &s->rcache[device];
+  }
+  HostRenderCache& c = *cp;
+  std::lock_guard<std::mutex> call_lock(c.mu);
   int rc = GRT_OK;
   auto H_ = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == GRT_OK) rc = grt_fail(GRT_EHIP, "%s: %s", what, hipGetErrorString(e));
     return e == hipSuccess;
   };
-  std::vector<float> h_sum;
-  std::vector<uint8_t> h_bgr;
+  const int bpp = pixels ? pitch / W : 0;
   do {
-    if (!H_(hipMalloc(&d_sum, nfl * sizeof(float)), "hipMalloc(accum)")) break;
-    if (ws_bytes && !H_(hipMalloc(&d_ws, ws_bytes), "hipMalloc(workspace)")) break;
-    if (!H_(hipMalloc(&d_rays, sizeof(uint64_t)), "hipMalloc(ray counter)")) break;
-    if (!H_(hipMemsetAsync(d_rays, 0, sizeof(uint64_t), nullptr), "hipMemsetAsync")) break;
-    if (!H_(hipEventCreate(&e0), "hipEventCreate") || !H_(hipEventCreate(&e1), "hipEventCreate")) break;
-    H_(hipEventRecord(e0, nullptr), "hipEventRecord");
-    rc = grt_render_accum_dev(s, o, shard, n_shards, samples, d_sum, d_ws, ws_bytes, d_rays, nullptr);
+    if (!H_(grow_device(&c.d_sum, &c.sum_cap, nfl * sizeof(float)), "hipMalloc(accum)")) break;
+    if (ws_bytes && !H_(grow_device(&c.d_ws, &c.ws_cap, ws_bytes), "hipMalloc(workspace)")) break;
+    if (!c.d_rays && !H_(hipMalloc(&c.d_rays, sizeof(uint64_t)), "hipMalloc(ray counter)")) break;
+    if (!c.e0 && (!H_(hipEventCreate(&c.e0), "hipEventCreate") || !H_(hipEventCreate(&c.e1), "hipEventCreate"))) break;
+    if (!H_(hipMemsetAsync(c.d_rays, 0, sizeof(uint64_t), nullptr), "hipMemsetAsync")) break;
+    H_(hipEventRecord(c.e0, nullptr), "hipEventRecord");
+    rc = grt_render_accum_dev(s, o, shard, n_shards, samples, c.d_sum, c.d_ws, ws_bytes, c.d_rays, nullptr);
     if (rc) break;
-    H_(hipEventRecord(e1, nullptr), "hipEventRecord");
-    if (pixels) {
-      if (!H_(hipMalloc(&d_bgr, (size_t)rows * W * 3), "hipMalloc(bgr)")) break;
-      rc = grt_tonemap_dev(d_sum, W, rows, samples, d_bgr, W * 3, nullptr);
+    H_(hipEventRecord(c.e1, nullptr), "hipEventRecord");
+    const unsigned tgrid = (unsigned)std::min<size_t>(((size_t)rows * W + 255) / 256, 8192);
+    if (pixels && pixels_mapped) {
+      hipLaunchKernelGGL(k_tonemap, dim3(tgrid), dim3(256), 0, nullptr, c.d_sum, W, rows, 1.0f / (float)samples, pixels_mapped, pitch, bpp,
+                         shard, n_shards);
+      if (!H_(hipGetLastError(), "k_tonemap")) break;
+    } else if (pixels) {
+      const size_t nb = (size_t)rows * W * 3;
+      if (!H_(grow_device(&c.d_bgr, &c.bgr_cap, nb), "hipMalloc(bgr)")) break;
+      if (!H_(grow_pinned(&c.h_bgr, &c.h_bgr_cap, nb), "hipHostMalloc(bgr)")) break;
+      rc = grt_tonemap_dev(c.d_sum, W, rows, samples, c.d_bgr, W * 3, nullptr);
       if (rc) break;
-      h_bgr.resize((size_t)rows * W * 3);
-      if (!H_(hipMemcpy(h_bgr.data(), d_bgr, h_bgr.size(), hipMemcpyDeviceToHost), "hipMemcpy(bgr)")) break;
+      if (!H_(hipMemcpyAsync(c.h_bgr, c.d_bgr, nb, hipMemcpyDeviceToHost, nullptr), "hipMemcpy(bgr)")) break;
     }
     if (rgb_sum) {
-      h_sum.resize(nfl);
-      if (!H_(hipMemcpy(h_sum.data(), d_sum, nfl * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(accum)")) break;
+      if (!H_(grow_pinned(&c.h_sum, &c.h_sum_cap, nfl * sizeof(float)), "hipHostMalloc(accum)")) break;
+      if (!H_(hipMemcpyAsync(c.h_sum, c.d_sum, nfl * sizeof(float), hipMemcpyDeviceToHost, nullptr), "hipMemcpy(accum)")) break;
     }
-    if (!H_(hipMemcpy(&res->rays, d_rays, sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(rays)")) break;
-    if (!H_(hipEventSynchronize(e1), "hipEventSynchronize")) break;
-    H_(hipEventElapsedTime(&res->ms, e0, e1), "hipEventElapsedTime");
+    if (!H_(hipMemcpy(&res->rays, c.d_rays, sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(rays)")) break;
+    if (!H_(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) break;
+    H_(hipEventElapsedTime(&res->ms, c.e0, c.e1), "hipEventElapsedTime");
   } while (0);
-  if (rc == GRT_OK) {
-    // scatter the packed bands to their rows (the collector of scene.go:123-132)
-    const int bpp = pixels ? pitch / W : 0;
+  if (rc == GRT_OK && (rgb_sum || (pixels && !pixels_mapped))) {
+    // the packed bands to their rows
     int lrow = 0;
     const int bands = (H + GRT_BAND_ROWS - 1) / GRT_BAND_ROWS;
     for (int b = shard; b < bands; b += n_shards)
       for (int y = b * GRT_BAND_ROWS; y < std::min(H, (b + 1) * GRT_BAND_ROWS); ++y, ++lrow) {
-        if (rgb_sum) memcpy(rgb_sum + (size_t)y * W * 3, h_sum.data() + (size_t)lrow * W * 3, (size_t)W * 3 * sizeof(float));
-        if (pixels) {
-          const uint8_t* src = h_bgr.data() + (size_t)lrow * W * 3;
+        if (rgb_sum) memcpy(rgb_sum + (size_t)y * W * 3, c.h_sum + (size_t)lrow * W * 3, (size_t)W * 3 * sizeof(float));
+        if (pixels && !pixels_mapped) {
+          const uint8_t* src = c.h_bgr + (size_t)lrow * W * 3;
           uint8_t* dst = pixels + (size_t)y * pitch;
-          for (int x = 0; x < W; ++x) {  // bytes beyond B,G,R stay untouched (scene.go:71-73)
-            dst[(size_t)x * bpp + 0] = src[3 * x + 0];
-            dst[(size_t)x * bpp + 1] = src[3 * x + 1];
-            dst[(size_t)x * bpp + 2] = src[3 * x + 2];
+          if (bpp == 3) {
+            memcpy(dst, src, (size_t)W * 3);
+          } else {
+            for (int x = 0; x < W; ++x) {  // bytes beyond B,G,R stay untouched (scene.go:71-73)
+              dst[(size_t)x * bpp + 0] = src[3 * x + 0];
+              dst[(size_t)x * bpp + 1] = src[3 * x + 1];
+              dst[(size_t)x * bpp + 2] = src[3 * x + 2];
+            }
           }
         }
       }
   }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipFree(d_sum);
-  (void)hipFree(d_ws);
-  (void)hipFree(d_rays);
-  (void)hipFree(d_bgr);
   if (rc) fail(rc);
 }
 
@@ -920,8 +956,36 @@ static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_
   int cur = 0;
   (void)hipGetDevice(&cur);
   std::vector<ShardResult> res(G);
+  // Zero-copy output: the caller's pixel buffer — a Go slice (main.go:64) or SDL texture memory
+  // (main.go:97) — is pinned and mapped for the length of the call and the tone-map kernels write into it.  Memory
+  // that cannot be registered (or GRT_NO_ZERO_COPY=1) goes through the pinned staging buffer instead.
+  std::vector<uint8_t*> mapped(G, nullptr);
+  bool registered = false;
+  if (pixels && !getenv("GRT_NO_ZERO_COPY")) {
+    (void)hipSetDevice(opts.first_device);
+    if (hipHostRegister(pixels, (size_t)s->d.height * (size_t)pitch, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+      registered = true;
+      for (int g = 0; g < G && registered; ++g) {
+        void* dp = nullptr;
+        if (hipSetDevice(opts.first_device + g) != hipSuccess || hipHostGetDevicePointer(&dp, pixels, 0) != hipSuccess || !dp) {
+          std::fill(mapped.begin(), mapped.end(), nullptr);
+          break;
+        }
+        mapped[g] = (uint8_t*)dp;
+      }
+      if (!mapped[G - 1]) std::fill(mapped.begin(), mapped.end(), nullptr);
+    } else {
+      (void)hipGetLastError();  // not an error of the call: the staging path serves
+    }
+  }
+  struct Unregister {
+    uint8_t* p;
+    ~Unregister() {
+      if (p) (void)hipHostUnregister(p);
+    }
+  } unregister{registered ? pixels : nullptr};
   if (G == 1) {
-    render_shard_host(s, &opts, opts.first_device, 0, 1, samples, rgb_sum, pixels, pitch, &res[0]);
+    render_shard_host(s, &opts, opts.first_device, 0, 1, samples, rgb_sum, pixels, mapped[0], pitch, &res[0]);
   } else {
     // a thread that cannot start (std::system_error) must not leave joinable threads behind: their destructors
     // would call std::terminate, which no function-try-block catches
@@ -929,7 +993,7 @@ static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_
     th.reserve(G);
     try {
       for (int g = 0; g < G; ++g)
-        th.emplace_back(render_shard_host, s, &opts, opts.first_device + g, g, G, samples, rgb_sum, pixels, pitch, &res[g]);
+        th.emplace_back(render_shard_host, s, &opts, opts.first_device + g, g, G, samples, rgb_sum, pixels, mapped[g], pitch, &res[g]);
     } catch (...) {
       for (auto& t : th) t.join();
       (void)hipSetDevice(cur);

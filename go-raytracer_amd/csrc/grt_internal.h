@@ -52,6 +52,26 @@ struct DeviceScene {
   uint8_t* tile_live = nullptr;  // per 8x8 tile of the frame: can a camera ray reach the scene bounds?
 };
 
+// What the host-buffer entry points (grt_render, grt_render_accum) keep per scene and device between calls:
+// device sums / chunk slabs / ray counter / packed bytes, pinned staging for the copies back, two events.
+// A frame then costs no hipMalloc / hipFree.  `mu` is held for the length of a call: calls
+// that share a scene and a device take turns.
+struct HostRenderCache {
+  std::mutex mu;
+  float* d_sum = nullptr;
+  size_t sum_cap = 0;
+  void* d_ws = nullptr;
+  size_t ws_cap = 0;
+  uint64_t* d_rays = nullptr;
+  uint8_t* d_bgr = nullptr;
+  size_t bgr_cap = 0;
+  float* h_sum = nullptr;  // pinned
+  size_t h_sum_cap = 0;
+  uint8_t* h_bgr = nullptr;  // pinned
+  size_t h_bgr_cap = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 struct grt_scene {
   grt_scene_desc d;
   std::vector<grt_prim> prims;
@@ -64,6 +84,7 @@ struct grt_scene {
   bool bvh_forced = false;  // hierarchy by request or by size: the parity kernel walks it too (else linear scan + FP64 re-test)
   std::mutex mu;
   std::map<int, DeviceScene> dev;  // staged copies, one per HIP device
+  std::map<int, HostRenderCache> rcache;  // grt_render's buffers, one set per HIP device (node addresses are stable)
 };
 
 struct KScene;

@@ -356,13 +356,17 @@ __global__ __launch_bounds__(256) void k_pm_accumulate(const float* __restrict__
 
 // scene.go:98-99 + WriteColor (scene.go:67-74): c = sum/samples; Gamma(2) = sqrt; Clamp =
 // min(1, c); uint8(255.99*c) truncation; bytes B,G,R.  bpp >= 3; byte 3.. untouched.
+// shard / n_shards: the rows of rgb_sum are a shard's packed bands (row r = row r % 8 of band shard + (r / 8) *
+// n_shards) and `bgr` is the WHOLE frame: the bytes go to their frame rows (n_shards == 1: row r is row r).
 __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ rgb_sum, int W, int rows,
                                                  float inv_samples, uint8_t* __restrict__ bgr, int pitch,
-                                                 int bpp) {
+                                                 int bpp, int shard, int n_shards) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)W * (size_t)rows, stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const size_t yy = i / (size_t)W, xx = i - yy * (size_t)W;
+    size_t yy = i / (size_t)W;
+    const size_t xx = i - yy * (size_t)W;
+    if (n_shards > 1) yy = ((size_t)shard + (yy >> 3) * (size_t)n_shards) * 8 + (yy & 7);
     const float* c = rgb_sum + i * 3;
     // Correctly rounded sqrt: the byte must not depend on a 1-ulp sqrt difference.  A negative
     // mean (only NormalMaterial produces one: (n+0.5)*0.5 with n = -1) gives NaN through

@@ -13,7 +13,7 @@ tag, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
-for cfg in ("c2", "c3", "c4", "c5"):
+for cfg in ("c2", "c3", "c4", "c4c", "c4pm", "c5"):
     ks = glob.glob(os.path.join(src, f"trace_{cfg}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
         lines = open(ks[0]).read().splitlines()[:9]

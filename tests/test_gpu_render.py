@@ -226,3 +226,29 @@ def test_empty_and_minimal_inputs(pkg, ob):
     orgb, onr = ob.OracleScene(one.flat).TraceSamples(np.array([[0, 0]], np.int32), 64, seed=3)
     assert (nr == onr).mean() > 0.95 and np.allclose(rgb.mean((0, 1)), orgb.mean((0, 1)), rtol=0.05, atol=1e-3)
     assert np.allclose(one.RenderAccum(64, seed=3)[0, 0], rgb.sum((0, 1)), rtol=1e-5)   # Render = the sum of its samples
+
+
+def test_render_output_paths_agree(pkg, monkeypatch):
+    """grt_render writes the caller's buffer through a mapped registration of it (zero copy: k_tonemap stores the
+    B,G,R bytes into the caller's memory) or, when GRT_NO_ZERO_COPY is set or the memory cannot be
+    registered, through pinned staging.  Same bytes either way, padding and 4th bytes untouched, for bpp 3, 4 and a
+    padded pitch, on an odd frame size; the scene's cached device buffers serve frames of changing sample counts."""
+    W, H = 203, 77
+    scene = pkg.tracer.NewScene(W, H, pkg.scenes.cornell_camera(W / H), pkg.scenes.cornell_objects())
+    for pitch in (3 * W, 4 * W, 4 * W + 20):
+        for spp in (6, 3, 9):
+            a = np.full(H * pitch + 5, 0x5A, np.uint8)[5:]          # an unaligned start address
+            scene.Render(a, pitch, spp, seed=8)
+            monkeypatch.setenv("GRT_NO_ZERO_COPY", "1")
+            b = np.full(H * pitch + 5, 0x5A, np.uint8)[5:]
+            scene.Render(b, pitch, spp, seed=8)
+            monkeypatch.delenv("GRT_NO_ZERO_COPY")
+            assert (a == b).all()
+            bpp = pitch // W
+            img = a.reshape(H, pitch)
+            assert img[:, : W * bpp].reshape(H, W, bpp)[..., :3].max() > 0
+            if bpp == 4:
+                assert (img[:, : W * bpp].reshape(H, W, 4)[..., 3] == 0x5A).all()
+            assert (img[:, W * bpp:] == 0x5A).all()
+    f = scene.RenderAccum(4, seed=8)
+    assert f.shape == (H, W, 3) and f.max() > 0

@@ -23,6 +23,9 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--cpu-queries", type=int, default=20000)
 ap.add_argument("--render-spp", type=int, default=16, help="photon-mapped trace() (scene.go:308-320) at this spp; 0 = skip")
+ap.add_argument("--only", choices=("all", "global", "caustic"), default="all",
+                help="gather launches of one map only (and no photon-mapped render): under rocprofv3 the k_gather_knn row of "
+                     "kernel_stats.csv is then that launch by itself")
 a = ap.parse_args()
 W, H = a.width, a.height
 lib = pkg._capi.load()
@@ -52,7 +55,11 @@ out = torch.empty_like(dP)
 ws = torch.empty(max(16, int(lib.grt_photon_gather_workspace_bytes(nq))), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 res = {}
+if a.only != "all":
+    a.render_spp = 0
 for name, pm, radius in (("global_r0", gmap, 0.0), ("caustic_r1", cmap, 1.0)):
+    if a.only != "all" and not name.startswith(a.only):
+        continue
     times = []
     for r in range(a.rounds + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,8 +73,9 @@ for name, pm, radius in (("global_r0", gmap, 0.0), ("caustic_r1", cmap, 1.0)):
     times.sort()
     ms = times[len(times) // 2]
     bytes_q = a.k * 28 + 36
-    res[name] = {"ms": ms, "queries_per_s": nq / ms * 1e3, "algorithmic_GBps": nq * bytes_q / ms / 1e6,
-                 "frac_of_8TBps": nq * bytes_q / ms / 1e6 / 8000.0, "mean_irradiance": out.mean(0).tolist()}
+    res[name] = {"ms": ms, "queries_per_s": nq / ms * 1e3, "mean_irradiance": out.mean(0).tolist()}
+    if radius == 0.0:   # SURVEY.md §8d's convention prices k photons per query; with a radius most queries accept far fewer
+        res[name].update({"algorithmic_GBps": nq * bytes_q / ms / 1e6, "frac_of_8TBps": nq * bytes_q / ms / 1e6 / 8000.0})
 
 cpu = None
 if a.cpu_queries > 0:
