@@ -887,16 +887,24 @@ GRT_DEV uint32_t select_kth(const uint32_t (&v)[RMAX], int count, int k, int lan
   return select_kth_bits<RMAX>(mv, j);
 }
 
-template <int RMAX, int GATHER_WAVES>
+// CARRY (round 2): the pool outlives the query.  A walk collects every photon within (estimate of r_k) x (1 + margin)
+// of the query — the ANCHOR — and keeps the positions in LDS; the pool is then the complete ball of radius R around
+// the anchor.  A following query q at distance a from the anchor computes its distances to the pooled photons (no
+// tree walk, no bucket loads), selects the k-th smallest r' among them, and is done when a + min(r', radius) <= R:
+// every photon within its reach is in the pool, so r' IS its k-th distance and the accepted set is exact.  Otherwise
+// the pool is rebuilt around q.  Neighbouring pixels are 0.6 units apart at C4 and r_k is 7: most queries are served
+// from the pool.
+template <int RMAX, int GATHER_WAVES, bool CARRY = false>
 __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(80))) void k_gather_knn(KdView T, const float* __restrict__ qpos,
                                                                   const float* __restrict__ qnrm, int n_q, int q_per_wave,
                                                                   float radius, int k, float* __restrict__ irrad,
                                                                   float* __restrict__ rk2_out,
-                                                                  unsigned long long* __restrict__ stats, float loose) {
+                                                                  unsigned long long* __restrict__ stats, float loose, float margin) {
   constexpr int CAP = 64 * RMAX;
   __shared__ float4 top_lo[GATHER_LDS_BOXES], top_hi[GATHER_LDS_BOXES];
   __shared__ float pool_d2[GATHER_WAVES][CAP];
   __shared__ int pool_ix[GATHER_WAVES][CAP];
+  __shared__ float pool_pos[CARRY ? GATHER_WAVES : 1][CARRY ? 3 * CAP : 1];  // CARRY: x[CAP], y[CAP], z[CAP] of the pooled photons
   __shared__ __attribute__((aligned(16))) int hist_all[GATHER_WAVES][GATHER_BINS];
   __shared__ float lut[4 * 256];  // costheta, sintheta, cosphi, sinphi (photon_mapping.go:90-93)
   for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = T.lut[i];
@@ -909,7 +917,11 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
   const int wave = sgpr(threadIdx.x >> 6);
   float* pd2 = pool_d2[wave];
   int* pix = pool_ix[wave];
+  float* ppos = pool_pos[CARRY ? wave : 0];
   int* hist = hist_all[wave];
+  // CARRY: the pool holds every photon within pool_R of (pax, pay, paz); pool_R < 0: no pool
+  float pool_R = -1.0f, pax = 0.0f, pay = 0.0f, paz = 0.0f;
+  int count = 0;
   const int q0 = (blockIdx.x * GATHER_WAVES + wave) * q_per_wave;
   const int q1 = min(q0 + q_per_wave, n_q);
   const float radius2 = radius * radius;
@@ -939,9 +951,52 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
       // worth tightening as soon as k photons are in the pool
       if (b < bound) bound = b, tight = b <= loose * prev_rk * prev_rk;
     }
-    int count = 0;
     uint32_t vb[RMAX];
     int st_nodes = 0, st_leaves = 0, st_sel = 0;  // tuning counters (stats != NULL only)
+    uint32_t Tk = 0x7f800000u;  // fewer than k photons: all of them
+    bool served = false;
+    if (CARRY && pool_R >= 0.0f) {  // wave-uniform
+      const float ax = qx - pax, ay = qy - pay, az = qz - paz;
+      const float da = sqrt32(fmaf(az, az, fmaf(ay, ay, ax * ax)));
+      if (da < pool_R) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const int j = lane + 64 * r;
+          vb[r] = 0xffffffffu;
+          if (64 * r < count) {  // wave-uniform
+            const int jj = j < count ? j : 0;
+            const float dx = ppos[jj] - qx, dy = ppos[CAP + jj] - qy, dz = ppos[2 * CAP + jj] - qz;  // same operation order as append_leaf
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (j < count) vb[r] = __float_as_uint(d2);
+          }
+        }
+        float reach = INFINITY;  // within this distance of the query the estimate needs every photon
+        if (count >= k) {
+          Tk = select_kth<RMAX>(vb, count, k, lane, hist);
+          st_sel++;
+          reach = sqrt32(__uint_as_float(Tk));
+        }
+        if (radius > 0.0f) reach = fminf(reach, radius);
+        served = (da + reach) * 1.00002f <= pool_R;
+        if (!served) Tk = 0x7f800000u;
+      }
+    }
+    if (!served) {
+    if (CARRY) {
+      count = 0;
+      pool_R = -1.0f;
+      // the walk below collects a ball around this query that later queries can be served from: the bound it starts
+      // with (radius, or the carried estimate of r_k) grows by the margin; a bound that is not tight yet (first query
+      // of a wave, a jump) is tightened by the walk itself and the next query rebuilds with the margin
+      if (bound < INFINITY && (tight || radius > 0.0f)) {
+        const float rb = sqrt32(bound) * (1.0f + margin);
+        bound = rb * rb;
+        tight = true;  // collect the whole ball; a pool that overflows is cut down to the k nearest as before
+      }
+    } else {
+      count = 0;
+    }
 
     // one step of the walk: the children of node `prefix` at level lvl (boxes off .. ), one per lane
     auto test_group = [&](int lvl, int off, int prefix, float bnd, float& d2box) -> unsigned long long {
@@ -974,6 +1029,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
       if (pass) {
         pd2[slot] = d2;
         pix[slot] = i;
+        if (CARRY) ppos[slot] = p.x, ppos[CAP + slot] = p.y, ppos[2 * CAP + slot] = p.z;
       }
       count += popc64(m);
       st_leaves++;
@@ -1008,11 +1064,14 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
           const int j = lane + 64 * r;
           const bool keep = vb[r] <= Tk;
           const int ix = pix[j];
+          float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+          if (CARRY) cx = ppos[j], cy = ppos[CAP + j], cz = ppos[2 * CAP + j];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
           const int slot = nc + mbcnt64(m);
           if (keep) {
             pd2[slot] = __uint_as_float(vb[r]);
             pix[slot] = ix;
+            if (CARRY) ppos[slot] = cx, ppos[CAP + slot] = cy, ppos[2 * CAP + slot] = cz;
           }
           nc += popc64(m);
         }
@@ -1098,18 +1157,26 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
 
     // final selection, then the loop of photon_mapping.go:138-161 over the pool
     load_pool();
-    uint32_t Tk = 0x7f800000u;  // fewer than k photons: all of them
     if (count >= k) Tk = select_kth<RMAX>(vb, count, k, lane, hist);
+    if (CARRY && T.n > 0 && bound < INFINITY) {
+      // every leaf was tested against a bound >= the final one, and a compaction keeps what lies within the new
+      // bound: the pool is the complete ball of that radius around this query
+      pool_R = sqrt32(bound) * 0.99999f;
+      pax = qx, pay = qy, paz = qz;
+    }
+    }  // !served
     const float nx = qnrm[3 * (size_t)qi], ny = qnrm[3 * (size_t)qi + 1], nz = qnrm[3 * (size_t)qi + 2];
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     uint32_t r2 = 0u;
     int found = 0;
+    bool found_any = false;  // some photon lies within reach (the radius, or anywhere)
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const int j = lane + 64 * r;
       if (64 * r < count) {  // wave-uniform
         const float d2 = __uint_as_float(vb[r]);
         bool acc = false;
+        found_any |= __builtin_amdgcn_ballot_w64(j < count && (radius == 0.0f || d2 <= radius2)) != 0ull;
         if (j < count && vb[r] <= Tk && (radius == 0.0f || d2 < radius2)) {  // :141
           const float4 pw = T.pwb[pix[j]];
           const int bits = __float_as_int(pw.w);
@@ -1138,13 +1205,15 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
       atomicAdd(stats + 2, (unsigned long long)st_sel + (count >= k ? 1 : 0));
       atomicAdd(stats + 3, (unsigned long long)count);
     }
+    // The k-th distance is known when the selection saw k photons inside the radius (a pool that reaches beyond the
+    // radius may hold k photons of which fewer than k count)
+    const bool kth_known = count >= k && (radius == 0.0f || __uint_as_float(Tk) <= radius2);
     if (lane == 0) {
       irrad[3 * (size_t)qi] = sx, irrad[3 * (size_t)qi + 1] = sy, irrad[3 * (size_t)qi + 2] = sz;
-      if (rk2_out) rk2_out[qi] = count >= k ? __uint_as_float(Tk) : (count ? INFINITY : -1.0f);
+      if (rk2_out) rk2_out[qi] = kth_known ? __uint_as_float(Tk) : (found_any ? INFINITY : -1.0f);
     }
-    // The bound handed to the next query must be the true k-th distance over ALL photons: it is
-    // when the selection saw k photons (a radius cut leaves fewer than k in the pool otherwise).
-    if (count >= k) prev_rk = sqrt32(__uint_as_float(Tk)) * 1.00001f, pqx = qx, pqy = qy, pqz = qz;
+    // The bound handed to the next query must be the true k-th distance over ALL photons.
+    if (kth_known) prev_rk = sqrt32(__uint_as_float(Tk)) * 1.00001f, pqx = qx, pqy = qy, pqz = qz;
     else prev_rk = -1.0f;
   }
 }
@@ -1175,18 +1244,27 @@ static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_
     GRT_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), st));
   }
   // waves per workgroup by pool size, so that the LDS pools of a CU's 32 waves fit in 160 KB
-#define GRT_GATHER_LAUNCH(RMAX, WAVES)                                                                               \
-  hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, \
-                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats, loose)
+#define GRT_GATHER_LAUNCH(RMAX, WAVES, CARRY)                                                                        \
+  hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES, CARRY>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, \
+                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats, loose, margin)
   const char* lenv = getenv("GRT_GATHER_LOOSE");  // tuning: carried bound / previous r_k^2 above which the bound counts as loose
   const float loose = lenv ? (float)atof(lenv) : 1.6f;
   const char* wenv = getenv("GRT_GATHER_WAVES");  // tuning: waves per workgroup of the k <= 128 kernel
   const int wsel = wenv ? atoi(wenv) : 16;
-  if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4);
-  else if (k <= 128 && wsel == 8) GRT_GATHER_LAUNCH(5, 8);
-  else if (k <= 128) GRT_GATHER_LAUNCH(5, 16);
-  else if (k <= 256) GRT_GATHER_LAUNCH(9, 8);
-  else GRT_GATHER_LAUNCH(17, 4);
+  // A/B: 1 = the pool outlives the query (CARRY).  MEASURED SLOWER at C4 (2.39 ms against 1.68 ms at margin 0.15, 2.63 at 0.35):
+  // a served query still pays its distances, its selection and its accumulation (60 % of a query), a rebuild walks a
+  // larger ball, an attempt that cannot be certified pays a selection for nothing, and the positions in LDS halve the
+  // waves per CU.  Exact all the same (tests/test_gpu_photon.py pass with it); kept for the record, off by default.
+  const char* cenv = getenv("GRT_GATHER_CARRY");
+  const bool carry = cenv ? atoi(cenv) != 0 : false;
+  const char* menv = getenv("GRT_GATHER_MARGIN");  // tuning: the pooled ball's radius = (estimate of r_k) x (1 + margin)
+  const float margin = menv ? (float)atof(menv) : 0.45f;
+  if (k <= 128 && carry) GRT_GATHER_LAUNCH(5, 8, true);
+  else if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4, false);
+  else if (k <= 128 && wsel == 8) GRT_GATHER_LAUNCH(5, 8, false);
+  else if (k <= 128) GRT_GATHER_LAUNCH(5, 16, false);
+  else if (k <= 256) GRT_GATHER_LAUNCH(9, 8, false);
+  else GRT_GATHER_LAUNCH(17, 4, false);
 #undef GRT_GATHER_LAUNCH
   GRT_HIP(hipGetLastError());
   if (d_stats) {
