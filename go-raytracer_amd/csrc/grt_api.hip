@@ -623,14 +623,41 @@ GRT_API int32_t grt_shard_rows(int32_t height, int32_t shard, int32_t n_shards) 
   return rows;
 }
 
-static int default_chunk_spp(int n_tiles, int samples) {
-  // Enough (tile, chunk) wave-items that the tail of the grid is short next to its body:
-  // ~32 items per wave slot (256 CUs x 32 waves; measured best at 1920x1080x1000: 8 chunks of
-  // 125 spp, 44.3 ms vs 48.8 ms unchunked), but no item shorter than 8 samples.
+static int default_chunk_spp(int n_tiles, int samples, bool hierarchy) {
+  // Enough (tile, chunk) wave-items that the tail of the grid is short next to its body — ~32 items per wave slot
+  // (256 CUs x 32 waves; measured best at 1920x1080x1000: 8 chunks of 125 spp, 44.3 ms vs 48.8 ms unchunked) — but
+  // chunks long enough that the wave's wait for its slowest pixel stays small next to the chunk (the end-of-item
+  // drain): at least 64 samples for the small-scene kernel (a shard of an 8-way split: 4.57 ms with
+  // 64-spp chunks, 4.72 with 16), 8 for the hierarchy kernel (its walks vary more than its path lengths).
   const int64_t want_items = 32 * 8192;
   int64_t n_chunks = std::max<int64_t>(1, want_items / std::max(1, n_tiles));
   int chunk = (int)((samples + n_chunks - 1) / n_chunks);
-  return std::min(samples, std::max(8, chunk));
+  chunk = std::max(hierarchy ? 8 : 64, chunk);
+  // the schedule table holds GRT_MAX_CHUNKS chunks, ~8 of them for the shrinking tail
+  chunk = std::max(chunk, (samples + (GRT_MAX_CHUNKS - 9)) / (GRT_MAX_CHUNKS - 8));
+  return std::min(samples, chunk);
+}
+
+// chunk_start[] for `samples` samples.  Explicit size: equal chunks (frames are then bit-identical however the work
+// is sharded).  Automatic: full chunks of `chunk`, and the last one to two chunks' worth of samples in halves — the
+// launch hands out items chunk by chunk, so its last wave-items are the short ones and the grid's tail (waves idle
+// while the last items finish) shrinks from half a full item to half a small one.
+static int chunk_schedule(int samples, int chunk, bool shrinking_tail, int* start) {
+  int n = 0, s = 0;
+  start[0] = 0;
+  if (!shrinking_tail) {
+    while (s < samples) start[++n] = (s = std::min(samples, s + chunk));
+    return n;
+  }
+  while (samples - s > 2 * chunk) start[++n] = (s += chunk);
+  int r = samples - s;
+  while (r > 16 && n < GRT_MAX_CHUNKS - 1) {
+    const int take = std::max(8, r / 2);
+    start[++n] = (s += take);
+    r -= take;
+  }
+  if (r > 0) start[++n] = (s += r);
+  return n;
 }
 
 static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shards, int samples, RenderJob* j) {
@@ -642,8 +669,11 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->rows_local = grt_shard_rows(s->d.height, shard, n_shards);
   j->tiles_x = (s->d.width + 7) / 8;
   j->n_tiles = j->tiles_x * local_bands;
-  j->chunk_spp = (o && o->chunk_spp > 0) ? std::min(o->chunk_spp, samples) : default_chunk_spp(j->n_tiles, samples);
-  j->n_chunks = (samples + j->chunk_spp - 1) / j->chunk_spp;
+  const bool explicit_chunk = o && o->chunk_spp > 0;
+  j->chunk_spp = explicit_chunk ? std::min(o->chunk_spp, samples) : default_chunk_spp(j->n_tiles, samples, s->use_bvh);
+  if ((samples + j->chunk_spp - 1) / j->chunk_spp > GRT_MAX_CHUNKS)
+    return grt_fail(GRT_ELIMIT, "chunk_spp %d cuts %d samples into more than %d chunks", j->chunk_spp, samples, GRT_MAX_CHUNKS);
+  j->n_chunks = chunk_schedule(samples, j->chunk_spp, !explicit_chunk && samples > j->chunk_spp && !getenv("GRT_UNIFORM_CHUNKS"), j->chunk_start);
   j->spp = samples;
   j->s_first = 0;
   j->pm.pos = j->pm.nrm = j->pm.w = nullptr;

@@ -14,12 +14,16 @@
 // Work decomposition of one shard of a frame.  A wave owns one 8x8 pixel tile for one chunk
 // of the sample range; tile rows coincide with the GRT_BAND_ROWS-row bands that are dealt
 // round-robin to shards, so a shard's tiles are whole.
+#define GRT_MAX_CHUNKS 63
 struct RenderJob {
   int shard, n_shards;  // this shard renders bands shard, shard+n_shards, ...
   int rows_local;       // rows this shard owns (packed, ascending)
   int tiles_x, n_tiles; // 8x8 tiles across, and in total for this shard
-  int n_chunks, chunk_spp, spp;
+  int n_chunks, chunk_spp, spp;  // chunk_spp: the size of a full chunk (explicit choice), or of the largest one (automatic schedule)
   int s_first;          // first sample index (sample-range sharding; 0 otherwise)
+  // chunk c renders samples s_first + [chunk_start[c], chunk_start[c+1]).  Equal chunks for an explicit chunk_spp; the
+  // automatic schedule ends with ever smaller chunks so that the last wave-items of a launch are short (grt_api.hip)
+  int chunk_start[GRT_MAX_CHUNKS + 1];
   PmOut pm;             // photon-mapped trace(): gather requests of this launch (pos == NULL: off)
   int pm_batch;         // samples per pixel the request arrays hold
   int shade_min;        // hierarchy scenes: lanes that must wait for shading before the wave shades (64: every level in lockstep)
@@ -142,8 +146,8 @@ void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
   const int lrow = lband * 8 + (lane >> 3);
   const bool valid = (x < S.W) & (y < S.H);
 
-  const int s0 = J.s_first + chunk * J.chunk_spp;
-  const int s_end = min(s0 + J.chunk_spp, J.s_first + J.spp);
+  const int s0 = J.s_first + J.chunk_start[chunk];
+  const int s_end = J.s_first + J.chunk_start[chunk + 1];
   uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
   float fx = (float)x, fy = (float)y;
 
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   const int y = (J.shard + lband * J.n_shards) * 8 + (lane >> 3);
   const int lrow = lband * 8 + (lane >> 3);
   const bool valid = (x < S.W) & (y < S.H);
-  const int s0 = J.s_first + chunk * J.chunk_spp;
-  const int s_end = min(s0 + J.chunk_spp, J.s_first + J.spp);
+  const int s0 = J.s_first + J.chunk_start[chunk];
+  const int s_end = J.s_first + J.chunk_start[chunk + 1];
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
   const float fx = (float)x, fy = (float)y;
   int n_rays = 0;
