@@ -259,6 +259,25 @@ def main():
                         "div and sqrt count 1 flop (SURVEY.md §8d); MFMA is not used: nothing here is a contraction",
             },
         }
+        if world == 1:
+            # the same frame with every 8x8 tile traced (no culling of tiles that look past the scene): VERDICT r01 asks
+            # for this number next to `value` wherever it is used
+            os.environ["GRT_NO_CULL"] = "1"       # read when a scene is staged
+            try:
+                plain = shard.ShardRenderer(pkg.scenes.cornell(W, H), S, 0, 1, seed=1, chunk_spp=args.chunk_spp, device=dev)
+            finally:
+                del os.environ["GRT_NO_CULL"]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_plain = 3
+            e0.record()
+            for _ in range(n_plain):
+                plain.render()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms_plain = e0.elapsed_time(e1) / n_plain
+            out["every_tile_traced"] = {"value": float(W) * H * S / ms_plain / 1e3, "unit": "Msamples/s", "ms_per_step": ms_plain,
+                                        "rays_per_sample": float(plain.ray_count.item()) / n_plain / (float(W) * H * S),
+                                        "note": "tile culling off (GRT_NO_CULL=1): the frame is bit-identical, 54 % of a 16:9 frame looks past the box"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, W, H)
         assert frame is not None and tuple(frame.shape) == (H, W, 3)
