@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--chunk-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed frames: no every-tile-traced leg, no CPU baseline (profiling runs: every k_pathtrace launch "
+                         "of the process is then the same launch)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks meet over gloo and check that their bands cover the frame (launcher test)")
     args = ap.parse_args()
@@ -259,7 +262,7 @@ def main():
                         "div and sqrt count 1 flop (SURVEY.md §8d); MFMA is not used: nothing here is a contraction",
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the same frame with every 8x8 tile traced (no culling of tiles that look past the scene): VERDICT r01 asks
             # for this number next to `value` wherever it is used
             os.environ["GRT_NO_CULL"] = "1"       # read when a scene is staged
@@ -278,7 +281,7 @@ def main():
             out["every_tile_traced"] = {"value": float(W) * H * S / ms_plain / 1e3, "unit": "Msamples/s", "ms_per_step": ms_plain,
                                         "rays_per_sample": float(plain.ray_count.item()) / n_plain / (float(W) * H * S),
                                         "note": "tile culling off (GRT_NO_CULL=1): the frame is bit-identical, 54 % of a 16:9 frame looks past the box"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(pkg, W, H)
         assert frame is not None and tuple(frame.shape) == (H, W, 3)
         print(json.dumps(out))
