@@ -147,6 +147,21 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
     }
     if (m.transparent) s->tobjects.push_back(i);
   }
+  // What one path can add to its pixel at most: throughput (a product of <= max_depth colours x reflectivities, each
+  // counted as >= 1) x the brightest source — an emitter's Color x Emittance (scene.go:279), NormalMaterial's 0.75
+  // (:275), or the direct light of the diffuse branch, <= its Color x the sum of the lights' colours (:322-346).
+  {
+    double gain = 1.0, source = 0.75, light_sum = 0.0, diffuse = 0.0;
+    auto cmax = [](const grt_material& m) { return std::max(std::fabs(m.color[0]), std::max(std::fabs(m.color[1]), std::fabs(m.color[2]))); };
+    for (int i : s->lights) light_sum += cmax(s->mats[s->prims[i].material]);
+    for (const grt_material& m : s->mats) {
+      gain = std::max(gain, cmax(m) * std::max(1.0, std::fabs(m.reflectivity)));
+      if (m.emittance > 0) source = std::max(source, cmax(m) * m.emittance);
+      diffuse = std::max(diffuse, cmax(m) * light_sum);
+    }
+    const double bound = std::pow(gain, std::max(1, desc->max_depth)) * std::max(source, diffuse);
+    s->radiance_log2 = std::isfinite(bound) ? (int)std::ceil(std::log2(std::max(bound, 1.0))) : 1024;
+  }
   *out = owner.release();
   return GRT_OK;
 } catch (...) {
@@ -680,7 +695,8 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   j->pm.view = 0;
   j->pm_batch = 0;
   const char* e = getenv("GRT_BVH_SHADE_MIN");  // A/B knob; 64 = every level in lockstep
-  j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : 10;
+  // 32 with the wave queue (C5: 0.252 s at 10, 0.245 at 16, 0.240 at 32, 0.254 at 48); round 1's lane = pixel loops ran best at 10
+  j->shade_min = e ? std::max(1, std::min(64, atoi(e))) : ((o && (o->flags & 15) == 8) ? 10 : 32);
   e = getenv("GRT_BVH_INNER_WEIGHT");
   j->inner_weight = e ? std::max(1, std::min(1024, atoi(e))) : 1;
   e = getenv("GRT_BVH_INNER_AGAIN");
@@ -688,6 +704,15 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   e = getenv("GRT_BVH_INNER_RUN");
   j->inner_run = e ? std::max(1, std::min(64, atoi(e))) : 4;
   j->no_octants = (o && (o->flags & 15) == 7) ? 1 : 0;  // variant 7: the min/max slab test (A/B against the octant tables)
+  // k_pathtrace_bvh sums a pixel's radiance in 64-bit fixed point: 2^e units per unit of radiance, e such that a chunk of
+  // 2^20 samples of the brightest thing a path can return stays below 2^62 (a function of the scene alone, so frames
+  // of different sample counts or shardings are made of the same numbers).
+  int longest = 0;
+  for (int c = 0; c < j->n_chunks; ++c) longest = std::max(longest, j->chunk_start[c + 1] - j->chunk_start[c]);
+  if (s->use_bvh && longest > (1 << 20))
+    return grt_fail(GRT_ELIMIT, "a chunk of %d samples is beyond the 2^20 the hierarchy kernel's fixed-point sums are sized for", longest);
+  const int e2 = std::max(-64, std::min(40, 62 - 20 - s->radiance_log2));
+  j->acc_scale = std::ldexp(1.0, e2), j->acc_inv = std::ldexp(1.0, -e2);
   return GRT_OK;
 }
 
@@ -734,7 +759,7 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   else if (s->use_bvh && variant == 5)  // every level in lockstep through path_advance (the state machine of the small scenes)
     hipLaunchKernelGGL((k_pathtrace<-1, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (s->use_bvh && variant == 6) {  // profiling build: d_ray_count holds 3 words (rays, inner nodes visited, objects tested)
-    if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..2]: a NULL counter was passed");
+    if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..15]: a NULL counter was passed");
     if (s->has_diffuse) return grt_fail(GRT_EINVAL, "render variant 6 (test counters) is built without the plain-diffuse branch");
     hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   } else if (s->use_bvh) {
@@ -744,6 +769,8 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
       hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
     else if (occ == 8 && ks.bvh_depth + 1 <= 20)
       hipLaunchKernelGGL((k_pathtrace_bvh<8, 20>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+    else if (variant == 8 && ks.bvh_depth + 1 <= 22)  // A/B: lane = pixel (round 1's loops) instead of the wave queue
+      hipLaunchKernelGGL((k_pathtrace_bvh<7, 22, false, false, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
     else if (occ >= 7 && ks.bvh_depth + 1 <= 22)
       hipLaunchKernelGGL((k_pathtrace_bvh<7, 22>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
     else if (occ == 5)
@@ -922,9 +949,9 @@ static void render_shard_host(grt_scene* s, const grt_opts* o, int device, int s
   do {
     if (!H_(grow_device(&c.d_sum, &c.sum_cap, nfl * sizeof(float)), "hipMalloc(accum)")) break;
     if (ws_bytes && !H_(grow_device(&c.d_ws, &c.ws_cap, ws_bytes), "hipMalloc(workspace)")) break;
-    if (!c.d_rays && !H_(hipMalloc(&c.d_rays, sizeof(uint64_t)), "hipMalloc(ray counter)")) break;
+    if (!c.d_rays && !H_(hipMalloc(&c.d_rays, 16 * sizeof(uint64_t)), "hipMalloc(ray counter)")) break;
     if (!c.e0 && (!H_(hipEventCreate(&c.e0), "hipEventCreate") || !H_(hipEventCreate(&c.e1), "hipEventCreate"))) break;
-    if (!H_(hipMemsetAsync(c.d_rays, 0, sizeof(uint64_t), nullptr), "hipMemsetAsync")) break;
+    if (!H_(hipMemsetAsync(c.d_rays, 0, 16 * sizeof(uint64_t), nullptr), "hipMemsetAsync")) break;
     H_(hipEventRecord(c.e0, nullptr), "hipEventRecord");
     rc = grt_render_accum_dev(s, o, shard, n_shards, samples, c.d_sum, c.d_ws, ws_bytes, c.d_rays, nullptr);
     if (rc) break;

@@ -380,9 +380,13 @@ struct PmOut {
 struct WaveQueue {
   int next, qend;          // same value in every live lane
   int s0, x0, y0;          // first sample of the chunk, tile origin
-  float* acc;              // LDS: 64 x RGB sums of this wave's tile
-  const uint32_t* pixkey;  // LDS: RNG pixel keys of the tile's 64 pixels
+  float* acc;              // LDS: 64 x RGB sums of this wave's tile            (mode 1 only)
+  const uint32_t* pixkey;  // LDS: RNG pixel keys of the tile's 64 pixels       (mode 1 only)
 };
+// path_shade's QUEUE parameter: 0 = every lane runs the samples of its own pixel; 1 = the wave queue above with the
+// sums in LDS (float atomics; the small scenes' A/B variant); 2 = the wave queue of k_pathtrace_bvh: the level's
+// radiance x throughput comes back in L.acc and the kernel adds it, in fixed point, to the sum the pixel's own lane
+// holds in registers — exact integer addition, so a frame does not depend on the order in which paths end.
 
 // Scene.intersect with the objects in LDS: the loop is fully unrolled, every lane reads the
 // same address (an LDS broadcast, no bank conflict), the compiler hoists the reads ahead of
@@ -689,7 +693,7 @@ GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, i
 
 // DIRECT: how the plain-diffuse branch finds its shadows: 0 linear loop (direct_light32), 1 the scene has
 // no plain-diffuse object (hierarchy scenes without one: the branch is compiled out), 2 hierarchy.
-template <bool QUEUE, int DIRECT = 0, bool VIEW = false>
+template <int QUEUE, int DIRECT = 0, bool VIEW = false>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t,
                         WaveQueue* Q = nullptr, const PmOut* pm = nullptr, int pm_base = 0, int* bvh_stack = nullptr,
@@ -735,7 +739,7 @@ GRT_DEV void path_advance(const KScene& S, const float4* __restrict__ tp, const 
 // every other surface, lights and Lambert walls included, shows IrradianceEst(p, n, 0, 100)) or, pm->view == 2,
 // trace()'s debugging block (scene.go:261-271: the estimate at the first hit).  The level leaves a gather request
 // with the path's throughput as its weight; nothing else carries radiance.
-template <bool QUEUE, int DIRECT, bool VIEW>
+template <int QUEUE, int DIRECT, bool VIEW>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
                         const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride, const float* octq) {
@@ -796,20 +800,25 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   if (QUEUE) {
     // only a terminating level carries radiance (emission, NormalMaterial, direct light)
     const f3 c = L.thr * rad;
-    if (term & ((c.x != 0.0f) | (c.y != 0.0f) | (c.z != 0.0f))) {
-      atomicAdd(Q->acc + 3 * L.pix, c.x);
-      atomicAdd(Q->acc + 3 * L.pix + 1, c.y);
-      atomicAdd(Q->acc + 3 * L.pix + 2, c.z);
+    if (QUEUE == 1) {
+      if (term & ((c.x != 0.0f) | (c.y != 0.0f) | (c.z != 0.0f))) {
+        atomicAdd(Q->acc + 3 * L.pix, c.x);
+        atomicAdd(Q->acc + 3 * L.pix + 1, c.y);
+        atomicAdd(Q->acc + 3 * L.pix + 2, c.z);
+      }
+    } else {
+      L.acc = c;                                    // QUEUE == 2: the caller adds it to the sum of the path's pixel
     }
     const unsigned long long ended = __ballot(term);  // every live lane sees the same mask
     const int q = Q->next + __builtin_amdgcn_mbcnt_hi((uint32_t)(ended >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ended, 0));
-    Q->next += __builtin_popcountll(ended);
+    if (QUEUE == 1) Q->next += __builtin_popcountll(ended);  // QUEUE == 2: the caller advances the counter (a path that has just been born has depth 1)
     if (term) {                                     // next (pixel, sample) of the wave's queue
       alive = q < Q->qend;
       L.pix = q & 63;
       L.s = Q->s0 + (q >> 6);
-      pix_key = Q->pixkey[L.pix];
-      fx = (float)(Q->x0 + (L.pix & 7)), fy = (float)(Q->y0 + (L.pix >> 3));
+      const int px = Q->x0 + (L.pix & 7), py = Q->y0 + (L.pix >> 3);
+      pix_key = QUEUE == 1 ? Q->pixkey[L.pix] : grt_rng_pixel_key(S.seed32, (uint32_t)py * (uint32_t)S.W + (uint32_t)px);
+      fx = (float)px, fy = (float)py;
       L.pkey = grt_rng_path_key(pix_key, (uint32_t)L.s);
       L.depth = 0;
       L.thr = mk3(1.0f, 1.0f, 1.0f);

@@ -81,6 +81,7 @@ struct grt_scene {
   double light_area = 0.0;
   bool use_bvh = false;
   bool has_diffuse = false;  // some object is plain diffuse (shadow rays, photon storage)
+  int radiance_log2 = 0;     // ceil(log2) of a bound on what one path can add to its pixel (fixed-point sums of k_pathtrace_bvh)
   bool bvh_forced = false;  // hierarchy by request or by size: the parity kernel walks it too (else linear scan + FP64 re-test)
   std::mutex mu;
   std::map<int, DeviceScene> dev;  // staged copies, one per HIP device

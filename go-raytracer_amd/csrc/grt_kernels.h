@@ -31,6 +31,7 @@ struct RenderJob {
   int inner_again;      // hierarchy scenes: another inner-node step follows at once while this many lanes still hold one ...
   int inner_run;        // ... up to this many steps per scheduling round
   int no_octants;       // A/B: scenes of <= 8 objects through the min/max slab test instead of the direction-octant tables
+  double acc_scale, acc_inv;  // k_pathtrace_bvh's fixed-point pixel sums: 2^e and 2^-e (make_job)
 };
 
 GRT_DEV unsigned long long wave_sum_u32(unsigned v) {
@@ -219,11 +220,20 @@ void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
 // reproducible and independent of sharding and of the thresholds.  The kernel is bound by memory
 // latency (dependent node fetches), so registers are spent sparingly — the walk keeps the ray
 // only in grid form (BvhRay) plus O and D — to hold 7 waves per SIMD.
-// COUNT (profiling build): ray_count[1] += inner nodes visited (two box tests, 32 B
-// each), ray_count[2] += objects tested (32 B each).
+// COUNT (profiling build; ray_count must then hold 16 words): ray_count[1] += inner nodes visited
+// (two box tests, 32 B each), ray_count[2] += objects tested (32 B each), [3..10] the schedule's step and lane counts.
 // DIFFUSE: the scene holds plain-diffuse objects: their shadow rays (and, with photon maps, their gather
 // requests) go through path_shade's hierarchy branch; without them that code is compiled out.
-template <int WAVES, int STACK, bool COUNT = false, bool DIFFUSE = false>
+// QUEUE (production): the wave's (pixel, sample) pairs are ONE queue — pair q is sample s0 + q / 64 of pixel q % 64 — and
+// a lane whose path has ended takes the next pair, whichever pixel it belongs to.  With lane = pixel the lanes of a
+// tile differ systematically in work (at C5 a pixel's primary hit decides how deep its paths go: the lanes of a tile
+// average 62 % of the busiest lane's work however long the chunk, tools/exp_c5_map.py), and 40 % of a wave's lanes sat
+// without work.  A path's radiance goes to the lane that owns its pixel (lane p holds pixel p's sum in registers):
+// v_readlane broadcasts of the few non-black paths of a shading step, added in FIXED POINT (J.acc_scale, a power of
+// two chosen from the scene's brightest source so that a chunk cannot overflow 63 bits).  Integer addition is exact,
+// so the sum does not depend on the order in which paths end: the frame stays reproducible and independent of sharding
+// and of the scheduling thresholds.  Pairs of pixels outside the frame (edge tiles) are born finished: no ray.
+template <int WAVES, int STACK, bool COUNT = false, bool DIFFUSE = false, bool QUEUE = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_pathtrace_bvh(
     KScene S, RenderJob J, float* __restrict__ out, unsigned long long* __restrict__ ray_count) {
   __shared__ int bvh_stack[STACK * 256];  // [wave][depth][lane]
@@ -238,13 +248,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   const bool valid = (x < S.W) & (y < S.H);
   const int s0 = J.s_first + J.chunk_start[chunk];
   const int s_end = J.s_first + J.chunk_start[chunk + 1];
-  const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
-  const float fx = (float)x, fy = (float)y;
+  uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
+  float fx = (float)x, fy = (float)y;
   int n_rays = 0;
-  bool alive = valid & (s0 < s_end);
-  if (S.tile_live && !S.tile_live[(J.shard + lband * J.n_shards) * J.tiles_x + tx]) alive = false;  // wave-uniform
+  const bool culled = S.tile_live && !S.tile_live[(J.shard + lband * J.n_shards) * J.tiles_x + tx];  // wave-uniform
+  bool alive = (QUEUE | valid) & (s0 < s_end) & !culled;
   LaneState L;
   lane_begin(S, fx, fy, pix_key, s0, L);
+  L.pix = lane;
+  WaveQueue Q;
+  Q.acc = nullptr, Q.pixkey = nullptr;
+  Q.s0 = s0, Q.x0 = tx * 8, Q.y0 = (J.shard + lband * J.n_shards) * 8;
+  Q.next = 64, Q.qend = 64 * (s_end - s0);
+  long long sum_x = 0, sum_y = 0, sum_z = 0;  // QUEUE: this lane's PIXEL, fixed point
   UnitRay r;
   BvhRay g;
   BvhWalk wk;
@@ -252,10 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   bvh_ray_setup(g, r, S.bvh_grid);
   bvh_walk_begin(wk);
   if (!alive) wk.ref = GRT_BVH_DONE;
+  if (QUEUE && !valid) wk.ref = GRT_BVH_DONE;  // born finished: it reaches shading as a miss and takes the next pair
   int* stack = bvh_stack + STACK * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's [depth][lane] block
   const int pm_base = DIFFUSE ? (lrow * S.W + x) * J.pm_batch - J.s_first : 0;  // request slot of sample s: pm_base + s
   unsigned long long zmask = __ballot(alive & ray_has_zero(r));  // lanes whose ray needs the careful box form
   int n_inner = 0, n_objs = 0;
+  unsigned c_steps[3] = {0, 0, 0}, c_lanes[3] = {0, 0, 0}, c_alive = 0, c_rounds = 0;  // COUNT: wave-uniform
   for (;;) {
     // Three kinds of step — an inner node, a leaf, a trace() level's shading — and every lane is
     // ready for exactly one of them (or has no samples left).  The wave runs the step most lanes
@@ -265,25 +283,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
     const unsigned long long mI = __ballot(at_inner), mL = __ballot(at_leaf), mS = __ballot(to_shade);
     const int nI = __builtin_popcountll(mI), nL = __builtin_popcountll(mL), nS = __builtin_popcountll(mS);
     if ((nI | nL | nS) == 0) break;
+    if (COUNT) c_rounds++, c_alive += nI + nL + nS;
     if (nS >= J.shade_min || (nI | nL) == 0) {
+      if (COUNT) c_steps[2]++, c_lanes[2] += nS;
+      int owner = 0;
+      f3 give = mk3(0.0f, 0.0f, 0.0f);
       if (to_shade) {
         float t;
         const int id = bvh_walk_result(wk, t);
-        n_rays++;  // scene.go:242
         Ray32 fr;
         ray_setup_unit(fr, r.O, r.D);
         L.O = r.O, L.D = r.D;
-        path_shade<false, DIFFUSE ? 2 : 1>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t, nullptr, &J.pm, pm_base, stack,
-                                           0);
+        if (QUEUE) {
+          owner = L.pix;
+          const int px = Q.x0 + (L.pix & 7), py = Q.y0 + (L.pix >> 3);
+          n_rays += (px < S.W) & (py < S.H);  // scene.go:242; a pair outside the frame made no call
+          const int base = DIFFUSE ? ((lband * 8 + (L.pix >> 3)) * S.W + px) * J.pm_batch - J.s_first : 0;
+          path_shade<2, DIFFUSE ? 2 : 1>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t, &Q, &J.pm, base, stack, 0);
+          give = L.acc;
+        } else {
+          n_rays++;  // scene.go:242
+          path_shade<0, DIFFUSE ? 2 : 1>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t, nullptr, &J.pm, pm_base,
+                                         stack, 0);
+        }
         if (alive) {
           r.O = L.O, r.D = L.D;
           bvh_ray_setup(g, r, S.bvh_grid);
           bvh_walk_begin(wk);
+          if (QUEUE && !((Q.x0 + (L.pix & 7) < S.W) & (Q.y0 + (L.pix >> 3) < S.H))) wk.ref = GRT_BVH_DONE;
+        }
+      }
+      if (QUEUE) {
+        Q.next += __builtin_popcountll(__ballot(to_shade & (L.depth == 1)));  // the pairs path_shade has just handed out
+        unsigned long long m = __ballot(to_shade & ((give.x != 0.0f) | (give.y != 0.0f) | (give.z != 0.0f)));
+        while (m) {  // usually empty: most levels carry no radiance
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const int p = __builtin_amdgcn_readlane(owner, l);
+          const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.x), l));
+          const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.y), l));
+          const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.z), l));
+          int me;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(me));
+          if (me == p) {
+            sum_x += (long long)((double)cx * J.acc_scale);
+            sum_y += (long long)((double)cy * J.acc_scale);
+            sum_z += (long long)((double)cz * J.acc_scale);
+          }
         }
       }
       zmask = (zmask & ~mS) | __ballot(to_shade & alive & ray_has_zero(r));
     } else if (nI * J.inner_weight >= nL * 4) {
-      if (COUNT) n_inner += at_inner;
+      if (COUNT) n_inner += at_inner, c_steps[0]++, c_lanes[0] += nI;
       if (at_inner) {
         if (zmask & mI) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
         else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
@@ -294,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         const bool again = bvh_at_inner(wk);
         const unsigned long long mA = __ballot(again);
         if (__builtin_popcountll(mA) < J.inner_again) break;
-        if (COUNT) n_inner += again;
+        if (COUNT) n_inner += again, c_steps[0]++, c_lanes[0] += __builtin_popcountll(mA), c_rounds++, c_alive += nI + nL + nS;
         if (again) {
           if (zmask & mA) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
           else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
@@ -302,6 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
       }
     } else {
       if (COUNT && at_leaf) n_objs += (~wk.ref) & 7;
+      if (COUNT) c_steps[1]++, c_lanes[1] += nL;
       if (at_leaf) {
         if (zmask & mL) bvh_leaf_step<true>(S.bvh_prims, r, S.bias, wk, stack, 0);
         else bvh_leaf_step<false>(S.bvh_prims, r, S.bias, wk, stack, 0);
@@ -310,16 +362,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   }
   if (valid) {
     float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
-    o[0] = L.acc.x;
-    o[1] = L.acc.y;
-    o[2] = L.acc.z;
+    if (QUEUE) {
+      o[0] = (float)((double)sum_x * J.acc_inv);
+      o[1] = (float)((double)sum_y * J.acc_inv);
+      o[2] = (float)((double)sum_z * J.acc_inv);
+    } else {
+      o[0] = L.acc.x;
+      o[1] = L.acc.y;
+      o[2] = L.acc.z;
+    }
+#ifdef GRT_COUNT_MAP  // experiment (tools/exp_c5_map.py, per-pixel loops only): the frame shows every pixel's work instead of its radiance
+    if (COUNT && !QUEUE) o[0] = (float)n_inner, o[1] = (float)n_objs, o[2] = (float)n_rays;
+#endif
   }
   if (ray_count) {
     unsigned long long tot = wave_sum_u32((unsigned)n_rays);
     if (lane == 0) atomicAdd(ray_count, tot);
     if (COUNT) {
       const unsigned long long ti = wave_sum_u32((unsigned)n_inner), to = wave_sum_u32((unsigned)n_objs);
-      if (lane == 0) atomicAdd(ray_count + 1, ti), atomicAdd(ray_count + 2, to);
+      if (lane == 0) {
+        atomicAdd(ray_count + 1, ti), atomicAdd(ray_count + 2, to);
+        // [3..5] wave steps of each kind (inner, leaf, shading), [6..8] the lanes that took part, [9] rounds (one per
+        // step), [10] lanes with work of any kind summed over the rounds
+        for (int k = 0; k < 3; ++k) atomicAdd(ray_count + 3 + k, (unsigned long long)c_steps[k]), atomicAdd(ray_count + 6 + k, (unsigned long long)c_lanes[k]);
+        atomicAdd(ray_count + 9, (unsigned long long)c_rounds), atomicAdd(ray_count + 10, (unsigned long long)c_alive);
+      }
     }
   }
 }

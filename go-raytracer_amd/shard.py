@@ -124,7 +124,7 @@ class SampleShardRenderer:
         nbytes = int(self.lib.grt_accum_workspace_bytes(scene.handle, C.byref(self.opts), 0, 1, max(1, self.count)))
         self.workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         self.workspace_bytes = nbytes
-        self.ray_count = torch.zeros(4, dtype=torch.int64, device=self.device)  # [0] rays; [1], [2]: test counters of variant 6
+        self.ray_count = torch.zeros(16, dtype=torch.int64, device=self.device)  # [0] rays; [1..10]: counters of variant 6
         self.render()  # stages the scene on this device so that later calls never allocate
         torch.cuda.synchronize(self.device)
         self.ray_count.zero_()

@@ -69,7 +69,10 @@ def test_deferred_shading_equals_lockstep_levels(pkg, monkeypatch):
     d = scene.RenderAccum(24, seed=3, variant=5)
     assert a.max() > 0
     assert (a == b).all() and (a == c).all()
-    assert (a == d).mean() > 0.9999, (a == d).mean()   # a wave with a zero-component ray takes the careful box form
+    # variant 5 adds a pixel's samples in FP32, in sample order; the production kernel adds them in fixed point (exact, any order)
+    assert np.allclose(a, d, rtol=2e-6, atol=1e-9) and (a == d).mean() > 0.999, (np.abs(a - d).max(), (a == d).mean())
+    e = scene.RenderAccum(24, seed=3, variant=8)     # lane = pixel loops (round 1's kernel): the same paths, FP32 sums
+    assert np.allclose(a, e, rtol=2e-6, atol=1e-9) and (a == e).mean() > 0.999
 
 
 def test_counting_build_counts_the_same_rays(pkg):
@@ -173,7 +176,7 @@ def test_auto_takes_the_hierarchy_above_208_objects(pkg, ob):
     lin = pkg.tracer.Scene(128, 96, cam, objs, accel=C.GRT_ACCEL_LINEAR)
     a, f, l = auto.RenderAccum(8, seed=5), forced.RenderAccum(8, seed=5), lin.RenderAccum(8, seed=5)
     assert (a == f).all()
-    assert (a == l).mean() > 0.999
+    assert np.allclose(a, l, rtol=2e-6, atol=1e-9) and (a == l).mean() > 0.99     # FP32 sums in sample order against exact fixed-point sums
     ids, t, _, _ = auto.PrimaryHits(0, 1)
     rid, rt, _ = ob.OracleScene(auto.flat).PrimaryHits(0, 1)
     assert (ids == rid).all()
@@ -204,8 +207,9 @@ def test_plain_diffuse_objects_shadow_rays_through_the_hierarchy(pkg, ob):
         same = (ln == bn) & (lr == br).all(-1)
         assert same.mean() > 0.999, same.mean()
         a, b = lin.RenderAccum(16, seed=2), bvh.RenderAccum(16, seed=2)     # k_pathtrace<0> vs k_pathtrace_bvh<.., DIFFUSE>
-        assert (a == b).mean() > 0.999 and a.max() > 0
-        assert (b == bvh.RenderAccum(16, seed=2, variant=5)).mean() > 0.999  # lockstep kernel, same branch
+        # the hierarchy kernel adds a pixel's samples in fixed point (exact), the others in FP32: equal to FP32 rounding
+        assert np.isclose(a, b, rtol=2e-6, atol=1e-9).mean() > 0.999 and a.max() > 0
+        assert np.isclose(b, bvh.RenderAccum(16, seed=2, variant=5), rtol=2e-6, atol=1e-9).mean() > 0.999  # lockstep kernel, same branch
     o = ob.OracleScene(bvh.flat).RenderAccum(16, seed=2) / 16
     g = b.astype(np.float64) / 16
     rel = np.abs(g.mean((0, 1)) - o.mean((0, 1))) / o.mean((0, 1))

@@ -72,6 +72,7 @@ ren.opts.flags = 6
 ren.render()
 torch.cuda.synchronize()
 c_rays, c_inner, c_objs = (float(v) for v in ren.ray_count[:3].tolist())
+c_sched = [float(v) for v in ren.ray_count[3:11].tolist()]
 ren.opts.flags = 0
 if world > 1:
     st = torch.tensor([wall, rays], dtype=torch.float64, device=dev)
@@ -95,6 +96,9 @@ if rank == 0:
                                  "bytes_per_ray": 32 * (c_inner + c_objs) / c_rays,
                                  "executed_TFLOPs": (50 * c_inner + fo * c_objs) / c_rays * rps / 1e12,
                                  "fetched_GBps": 32 * (c_inner + c_objs) / c_rays * rps / 1e9,
+                                 "schedule": {"wave_steps_inner_leaf_shade": c_sched[0:3],
+                                              "lanes_per_step_inner_leaf_shade": [c_sched[3 + k] / max(1.0, c_sched[k]) for k in range(3)],
+                                              "lanes_with_work_per_round": c_sched[7] / max(1.0, c_sched[6])},
                                  "note": "rank 0's sample range, counting build (opts.flags = 6); the reference would run "
                                          f"{a.spheres + 2} object tests per ray (scene.go:173)"}
     if a.cpu_spheres > 0 and world == 1:
