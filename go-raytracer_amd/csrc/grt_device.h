@@ -306,7 +306,8 @@ GRT_DEV int surface32(const KScene& S, int id, const Ray32& r, float t, f3& p, f
 // reference's final Unit() is not repeated.
 GRT_DEV f3 sample_hemi32(f3 n, float u1, float u2) {
   float r2s = sqrt32(u2);
-  f3 u = fabsf(n.x) > 0.1f ? mk3(n.z, 0.0f, -n.x) : mk3(0.0f, -n.z, n.y);  // (0,1,0)xn | (1,0,0)xn
+  const bool big_x = fabsf(n.x) > 0.1f;
+  f3 u = big_x ? mk3(n.z, 0.0f, -n.x) : mk3(0.0f, -n.z, n.y);  // (0,1,0)xn | (1,0,0)xn
   u = unit3(u);
   f3 v = cross3(n, u);
   float c = __builtin_amdgcn_cosf(u1) * r2s, s = __builtin_amdgcn_sinf(u1) * r2s;
@@ -321,19 +322,21 @@ GRT_DEV f3 reflect32(f3 v, f3 n) { return fma3(n, -2.0f * dot3(v, n), v); }
 // ratio, 1/ratio and r0 = ((1-ratio)/(1+ratio))^2 for both orientations (no reciprocal in the kernel).  The
 // refracted direction r1 + r2 has |r1|^2 + |r2|^2 = 1 by construction: not normalised again.
 GRT_DEV bool refract32(f3 v, f3 n, float4 m2, float xi, f3& out) {
-  const bool flip = dot3(v, n) >= 0.0f;
+  // With |v| = |n| = 1: r1 = (v + rn cosi) ratio has |r1|^2 = ratio^2 (1 - cosi^2), so the reference's
+  // r1 + rn (-sqrt|1 - |r1|^2|) is v ratio + rn (ratio cosi - sqrt(1 - ratio^2 sini^2)) — Snell's form, one square
+  // root instead of two — and total internal reflection (ratio sini > 1) is 1 - ratio^2 sini^2 < 0.
+  const float dvn = dot3(v, n);
+  const bool flip = dvn >= 0.0f;                   // rn = flip ? -n : n
   const float ratio = flip ? m2.y : m2.x;
   float r0 = flip ? m2.w : m2.z;
-  const f3 rn = flip ? -n : n;
-  float cosi = fminf(-dot3(v, rn), 1.0f);
-  float sini = sqrt32(1.0f - cosi * cosi);
-  bool tir = ratio * sini > 1.0f;
-  float m = 1.0f - cosi, mm = m * m;
+  const float cosi = fminf(fabsf(dvn), 1.0f);      // min(-v.rn, 1)
+  const float sin2 = fmaf(-cosi, cosi, 1.0f);
+  const float k2 = fmaf(-(ratio * ratio), sin2, 1.0f);
+  const float m = 1.0f - cosi, mm = m * m;
   r0 = fmaf(1.0f - r0, mm * mm * m, r0);
-  if (tir | (r0 > xi)) return false;
-  f3 r1 = fma3(rn, cosi, v) * ratio;
-  float k = -sqrt32(fabsf(1.0f - dot3(r1, r1)));
-  out = fma3(rn, k, r1);
+  if ((k2 < 0.0f) | (r0 > xi)) return false;
+  const float c = fmaf(ratio, cosi, -sqrt32(k2));
+  out = fma3(n, flip ? -c : c, v * ratio);
   return true;
 }
 
@@ -786,8 +789,8 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   // a scattering material at the last level: the recursive call returns black (scene.go:238)
   bool term = !hit | is_normal | is_emit | is_diff | (L.depth + 1 >= S.max_depth);
   f3 dir = n;
+  if ((is_metal | is_glass) & !term) dir = reflect32(r.D, n);  // metal; glass that reflects (total internal reflection, Schlick)
   if (is_metal & !term) {                           // scene.go:287-294
-    dir = reflect32(r.D, n);
     if (m1.y != 0.0f) {
       f3 fz = sample_hemi32(n, grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 0)), grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 1)));
       dir = unit3(fma3(fz, m1.y, dir));             // keep |D| = 1 (direction unchanged)
@@ -847,7 +850,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
       L.thr = L.thr * (VIEW ? color : color * m1.x);  // f.Times(...) (scene.go:213) | .Times(m.Color).Scale(m.Reflectivity) (:293)
     } else {                                        // scene.go:295-304; u1 is the roulette draw
       f3 d;
-      if (!refract32(r.D, n, tm[GRT_MAT_STRIDE * m + 2], u1, d)) d = reflect32(r.D, n);
+      if (!refract32(r.D, n, tm[GRT_MAT_STRIDE * m + 2], u1, d)) d = dir;
       L.D = d;
     }
   }

@@ -16,7 +16,7 @@ trace() { # name script args...
   return $rc
 }
 trace c3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-extras || exit 1
-trace c2 "$ROOT/tools/bench_primary.py" --rounds 5 || exit 1
+trace c2 "$ROOT/tools/bench_primary.py" --rounds 10 || exit 1
 trace c4 "$ROOT/tools/bench_photon.py" --cpu-queries 0 --rounds 5 --only global || exit 1   # k_gather_knn row = the global-map gather alone
 trace c4c "$ROOT/tools/bench_photon.py" --cpu-queries 0 --rounds 5 --only caustic || exit 1
 trace c4pm "$ROOT/tools/bench_photon.py" --cpu-queries 0 --rounds 1 || exit 1                 # incl. the photon-mapped render

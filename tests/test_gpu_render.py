@@ -252,3 +252,35 @@ def test_render_output_paths_agree(pkg, monkeypatch):
             assert (img[:, W * bpp:] == 0x5A).all()
     f = scene.RenderAccum(4, seed=8)
     assert f.shape == (H, W, 3) and f.max() > 0
+
+
+def test_in_library_shards_assemble_the_single_device_frame(pkg, monkeypatch):
+    """grt_opts.n_devices = G: one host thread per shard, interleaved 8-row bands, every shard writes its own rows of
+    the caller's buffer (what the single-process Go host would use on an 8-GPU node).  On a one-GPU box the shards run
+    on device 0 (GRT_SHARDS_ON_ONE_DEVICE: the library's test seam; the threads, band copies and totals are those of a
+    G-device run).  At a fixed chunk size the assembled frame is the one-shard frame bit for bit — sums, bytes through
+    the mapped buffer and through staging, 4th bytes and pitch padding untouched, ray totals equal."""
+    W, H = 203, 77                                       # 10 bands, the last one 5 rows high
+    scene = pkg.tracer.NewScene(W, H, pkg.scenes.cornell_camera(W / H), pkg.scenes.cornell_objects())
+    lib = pkg._capi.load()
+    one = scene.RenderAccum(12, seed=3, chunk_spp=4)
+    rays = int(lib.grt_last_ray_count())
+    pitch = 4 * W + 12
+    px1 = np.full(H * pitch, 0x5A, np.uint8)
+    scene.Render(px1, pitch, 12, seed=3, chunk_spp=4)
+    monkeypatch.setenv("GRT_SHARDS_ON_ONE_DEVICE", "1")
+    for G in (2, 3, 8, 13):                               # 13 > the band count: three shards own nothing
+        got = scene.RenderAccum(12, seed=3, chunk_spp=4, n_devices=G)
+        assert (got == one).all(), G
+        assert int(lib.grt_last_ray_count()) == rays
+        for staging in (False, True):
+            if staging:
+                monkeypatch.setenv("GRT_NO_ZERO_COPY", "1")
+            px = np.full(H * pitch, 0x5A, np.uint8)
+            scene.Render(px, pitch, 12, seed=3, chunk_spp=4, n_devices=G)
+            if staging:
+                monkeypatch.delenv("GRT_NO_ZERO_COPY")
+            assert (px == px1).all(), (G, staging)
+    monkeypatch.delenv("GRT_SHARDS_ON_ONE_DEVICE")
+    with pytest.raises(pkg._capi.GrtError, match="devices"):
+        scene.RenderAccum(2, seed=3, n_devices=64)        # more devices than the box has: refused, not clamped
