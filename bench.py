@@ -117,6 +117,43 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def other_configs():
+    """The other measured configurations of SURVEY.md §8d next to the headline one, so that the driver's bench record holds
+    them too: C2 (primary-ray sweep), C4 (photon build + k-nearest gather), C5 (10^6 spheres through the hierarchy).  Each is
+    its own tool run as a child process after the timed region (a fresh process per scene size keeps this one's memory flat);
+    a leg that fails or runs out of time is recorded as such and never fails the bench."""
+    import subprocess
+
+    def leg(script, *argv):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *argv], capture_output=True, text=True, timeout=180)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            return json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001 (a timeout or a parse error of a side leg)
+            return {"error": repr(e)[:300]}
+
+    res = {}
+    d = leg("bench_primary.py")
+    res["c2_primary_sweep_3840x2160"] = d if "error" in d else {
+        "kernel_ms": d["roofline_variant"]["kernel_ms"], "rays_per_s": d["roofline_variant"]["rays_per_s"],
+        "frac_of_fp32_peak": d["roofline_variant"]["frac"], "parity_kernel_ms": d["parity_variant"]["kernel_ms"],
+        "fp64_retest_fraction": d["parity_variant"]["fp64_retest_fraction"]}
+    d = leg("bench_photon.py", "--cpu-queries", "0")
+    if "error" in d:
+        res["c4_photon_1e6"] = d
+    else:
+        g = d["gather"]["global_r0"]
+        res["c4_photon_1e6"] = {"global_gather_ms": g["ms"], "queries_per_s": g["queries_per_s"], "frac_of_8TBps": g["frac_of_8TBps"],
+                                "caustic_gather_ms": d["gather"]["caustic_r1"]["ms"],
+                                "build_global_s": d["emission"]["global_s"], "build_caustic_s": d["emission"]["caustic_s"],
+                                "photon_mapped_render_Msamples_per_s": (d.get("photon_mapped_render") or {}).get("Msamples_per_s")}
+    d = leg("bench_spheres.py", "--cpu-spheres", "0")
+    res["c5_spheres_1e6_256spp"] = d if "error" in d else {
+        "frame_s": d["frame_s"], "Msamples_per_s": d["Msamples_per_s"], "rays_per_s": d["rays_per_s"],
+        "inner_nodes_per_ray": d.get("executed_tests", {}).get("inner_nodes_per_ray")}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +167,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed frames: no every-tile-traced leg, no CPU baseline (profiling runs: every k_pathtrace launch "
                          "of the process is then the same launch)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 / C5 legs (tools/bench_*.py run as child processes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks meet over gloo and check that their bands cover the frame (launcher test)")
     args = ap.parse_args()
@@ -283,6 +321,8 @@ def main():
                                         "note": "tile culling off (GRT_NO_CULL=1): the frame is bit-identical, 54 % of a 16:9 frame looks past the box"}
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(pkg, W, H)
+        if world == 1 and not args.no_extras and not args.no_other_configs:
+            out["other_configs"] = other_configs()
         assert frame is not None and tuple(frame.shape) == (H, W, 3)
         print(json.dumps(out))
     if world > 1:
