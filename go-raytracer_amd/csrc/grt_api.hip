@@ -761,7 +761,11 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
   else if (s->use_bvh && variant == 6) {  // profiling build: d_ray_count holds 3 words (rays, inner nodes visited, objects tested)
     if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 6 counts into d_ray_count[0..15]: a NULL counter was passed");
     if (s->has_diffuse) return grt_fail(GRT_EINVAL, "render variant 6 (test counters) is built without the plain-diffuse branch");
+#ifdef GRT_COUNT_MAP  // experiment build (tools/exp_c5_map.py): per-pixel work of the lane = pixel loops written into the frame
+    hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true, false, false>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+#else
     hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
+#endif
   } else if (s->use_bvh) {
     const char* e = getenv("GRT_BVH_OCC");
     const int occ = e ? atoi(e) : 7;
