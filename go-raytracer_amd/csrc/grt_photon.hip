@@ -49,6 +49,7 @@ struct grt_pmap {
   float4* d_boxes = nullptr; // [2 * n_boxes]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
   int* d_order = nullptr;    // [n+1] slot -> storage (emission) index (grt_photon_read)
+  float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};  // bounds of the stored photons (the Morton grid gather queries are sorted on)
 };
 
 // ---- emission ---------------------------------------------------------------------------------
@@ -417,6 +418,16 @@ static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, gr
     }
     PTRY(hipGetLastError());
     PTRY(hipDeviceSynchronize());
+    // the union of the top-level boxes
+    const int n_top = 1 << b0;
+    std::vector<float4> top(2 * (size_t)n_top);
+    PTRY(hipMemcpy(top.data(), pm->d_boxes, (size_t)n_top * sizeof(float4), hipMemcpyDeviceToHost));
+    PTRY(hipMemcpy(top.data() + n_top, pm->d_boxes + total, (size_t)n_top * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; ++c) pm->bmin[c] = INFINITY, pm->bmax[c] = -INFINITY;
+    for (int i = 0; i < n_top; ++i) {
+      const float lo[3] = {top[i].x, top[i].y, top[i].z}, hi[3] = {top[n_top + i].x, top[n_top + i].y, top[n_top + i].z};
+      for (int c = 0; c < 3; ++c) pm->bmin[c] = std::min(pm->bmin[c], lo[c]), pm->bmax[c] = std::max(pm->bmax[c], hi[c]);
+    }
   } while (0);
   (void)hipFree(d_k0), (void)hipFree(d_k1), (void)hipFree(d_p1), (void)hipFree(d_segbox), (void)hipFree(d_tmp);
   return rc;
@@ -1218,11 +1229,91 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
   }
 }
 
+#include "grt_gather_group.h"
+
 #define GRT_GATHER_MAX_K 512
 
-GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (uint64_t)n * sizeof(float) : 0; }
+// Workspace of a gather of n queries: the k-th squared distances (n floats, what the caller reads), then the scratch of
+// the Morton sort that puts neighbouring queries into one wave of k_gather_group (keys and query indices, in and out,
+// and hipCUB's temporary storage).
+static bool gather_group_enabled() {  // A/B experiment, off by default (grt_gather_group.h)
+  const char* e = getenv("GRT_GATHER_GROUP");
+  return e && atoi(e) != 0;
+}
+struct GatherWs {
+  float* rk2;
+  uint32_t *k0, *k1;
+  int *v0, *v1;
+  void* tmp;
+  size_t tmp_bytes;
+};
+static uint64_t gather_ws_carve(void* base, int n, GatherWs* w) {
+  auto al = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+  const uint64_t words = al((uint64_t)n * 4);
+  if (!gather_group_enabled()) {  // the k-th squared distances only
+    if (w) *w = GatherWs{(float*)base, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return (uint64_t)n * 4;
+  }
+  size_t tmp = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int*)nullptr, (int*)nullptr, n, 0, 30);
+  if (w) {
+    char* b = (char*)base;
+    w->rk2 = (float*)b;
+    w->k0 = (uint32_t*)(b + words), w->k1 = (uint32_t*)(b + 2 * words);
+    w->v0 = (int*)(b + 3 * words), w->v1 = (int*)(b + 4 * words);
+    w->tmp = b + 5 * words, w->tmp_bytes = tmp;
+  }
+  return 5 * words + al(tmp);
+}
+GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? gather_ws_carve(nullptr, n, nullptr) : 0; }
 
-// Queries served back to back by one wave (they share the carried bound).  GRT_GATHER_QPW
+GRT_DEV uint32_t morton_spread10(uint32_t v) {  // 10 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+// keys[i] = 30-bit Morton code of query i on a 1024^3 grid over the map's bounds (NaN position = no query: last), vals[i] = i
+__global__ __launch_bounds__(256) void k_gather_keys(const float* __restrict__ qpos, int n, float ox, float oy, float oz, float sx, float sy,
+                                                     float sz, uint32_t* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = qpos[3 * (size_t)i], y = qpos[3 * (size_t)i + 1], z = qpos[3 * (size_t)i + 2];
+  uint32_t key = 0x3fffffffu;
+  if (x == x) {
+    const uint32_t ux = (uint32_t)fminf(fmaxf((x - ox) * sx, 0.0f), 1023.0f), uy = (uint32_t)fminf(fmaxf((y - oy) * sy, 0.0f), 1023.0f),
+                   uz = (uint32_t)fminf(fmaxf((z - oz) * sz, 0.0f), 1023.0f);
+    key = morton_spread10(ux) | (morton_spread10(uy) << 1) | (morton_spread10(uz) << 2);
+  }
+  keys[i] = key;
+  vals[i] = i;
+}
+// Sorts the queries into Morton order: *perm = query index of sorted slot i (in the workspace).
+static int gather_sort(const grt_pmap* pm, const float* d_pos, int n, void* d_workspace, hipStream_t st, const int** perm) {
+  GatherWs w;
+  gather_ws_carve(d_workspace, n, &w);
+  float sc[3];
+  for (int c = 0; c < 3; ++c) {
+    const float ext = pm->bmax[c] - pm->bmin[c];
+    sc[c] = ext > 0.0f ? 1023.99f / ext : 0.0f;
+  }
+  hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_pos, n, pm->bmin[0], pm->bmin[1], pm->bmin[2], sc[0],
+                     sc[1], sc[2], w.k0, w.v0);
+  GRT_HIP(hipGetLastError());
+  GRT_HIP(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, (const uint32_t*)w.k0, w.k1, (const int*)w.v0, w.v1, n, 0, 30, st));
+  *perm = w.v1;
+  return GRT_OK;
+}
+// Which kernel serves a gather: k_gather_knn (one wave per query, the caller's order).  GRT_GATHER_GROUP=1 (an A/B
+// experiment, MEASURED SLOWER: grt_gather_group.h) takes k_gather_group for k <= 128: one group of 64 queries per wave, the
+// queries sorted into Morton order when the caller brought a workspace (which is then larger, see gather_ws_carve).
+static bool gather_grouped(int n, int k, const void* d_workspace) {
+  (void)n, (void)d_workspace;
+  return k <= 128 && gather_group_enabled();
+}
+
+// Queries served back to back by one wave of k_gather_knn (they share the carried bound).  GRT_GATHER_QPW
 // overrides the default for tuning runs (tools/bench_photon.py).
 static int gather_qpw(float radius) {
   const char* e = getenv("GRT_GATHER_QPW");
@@ -1232,16 +1323,17 @@ static int gather_qpw(float radius) {
   return v > 0 ? v : (radius > 0.0f ? 8 : 24);
 }
 
+// perm != NULL (or `grouped`): k_gather_group over the queries in the order perm names (NULL: the caller's order).
 static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
-                         float* d_rk2, hipStream_t st) {
+                         float* d_rk2, hipStream_t st, bool grouped = false, const int* perm = nullptr) {
   const int qpw = gather_qpw(radius);
   KdView T = {pm->d_boxes, pm->d_pos3, pm->d_pwb, pm->d_lut, pm->n, pm->depth, pm->levels, pm->b0, pm->n_boxes};
   // GRT_GATHER_STATS=1 (tuning runs only): per-launch totals of node steps, leaf buckets read,
   // selections and pool sizes on stderr; allocates and synchronises, so never set in production.
   unsigned long long* d_stats = nullptr;
   if (getenv("GRT_GATHER_STATS")) {
-    GRT_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
-    GRT_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), st));
+    GRT_HIP(hipMalloc(&d_stats, 16 * sizeof(unsigned long long)));
+    GRT_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
   // waves per workgroup by pool size, so that the LDS pools of a CU's 32 waves fit in 160 KB
 #define GRT_GATHER_LAUNCH(RMAX, WAVES, CARRY)                                                                        \
@@ -1259,7 +1351,11 @@ static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_
   const bool carry = cenv ? atoi(cenv) != 0 : false;
   const char* menv = getenv("GRT_GATHER_MARGIN");  // tuning: the pooled ball's radius = (estimate of r_k) x (1 + margin)
   const float margin = menv ? (float)atof(menv) : 0.45f;
-  if (k <= 128 && carry) GRT_GATHER_LAUNCH(5, 8, true);
+  const bool group = grouped && k <= 128;
+  if (group) {
+    const unsigned grid = (unsigned)(((n + 63) / 64 + 3) / 4);
+    hipLaunchKernelGGL((k_gather_group<512, 4>), dim3(grid), dim3(256), 0, st, T, d_pos, d_nrm, perm, n, radius, k, d_irrad, d_rk2, d_stats);
+  } else if (k <= 128 && carry) GRT_GATHER_LAUNCH(5, 8, true);
   else if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4, false);
   else if (k <= 128 && wsel == 8) GRT_GATHER_LAUNCH(5, 8, false);
   else if (k <= 128) GRT_GATHER_LAUNCH(5, 16, false);
@@ -1268,10 +1364,17 @@ static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_
 #undef GRT_GATHER_LAUNCH
   GRT_HIP(hipGetLastError());
   if (d_stats) {
-    unsigned long long h[4];
+    unsigned long long h[16];
     GRT_HIP(hipStreamSynchronize(st));
     GRT_HIP(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
+    if (k <= 128 && group)
+      fprintf(stderr, "[gather stats] n=%d k=%d radius=%g groups: %.0f per 64 queries, pool %.1f, passes %.2f per group, %.3f splits per 64 queries\n", n,
+              k, (double)radius, (double)h[0] * 64 / n, (double)h[1] / std::max(1.0, (double)h[0]), (double)h[2] / std::max(1.0, (double)h[0]),
+              (double)h[3] * 64 / n);
+    if (group) fprintf(stderr, "   per group: node steps %.1f, leaf buckets %.1f, selections over the pool %.2f\n", h[7] / std::max(1.0, (double)h[0]), h[8] / std::max(1.0, (double)h[0]), h[9] / std::max(1.0, (double)h[0]));
+    if (group) fprintf(stderr, "   mean rho %.2f B %.2f P %.2f per group\n", h[4] * 1e-3 / std::max(1.0, (double)h[0]), h[5] * 1e-3 / std::max(1.0, (double)h[0]), h[6] * 1e-3 / std::max(1.0, (double)h[0]));
+    else
     fprintf(stderr, "[gather stats] n=%d k=%d radius=%g qpw=%d: node steps %.1f, leaf buckets %.2f, selections %.2f, pool %.1f per query\n",
             n, k, (double)radius, qpw, (double)h[0] / n, (double)h[1] / n, (double)h[2] / n, (double)h[3] / n);
   }
@@ -1292,7 +1395,13 @@ GRT_API int grt_photon_gather_dev(const grt_pmap* pm, const float* d_pos, const 
   int rc = gather_check(pm, d_pos, d_nrm, d_irrad, n, k);
   if (rc) return rc;
   if (n == 0) return GRT_OK;
-  return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream);
+  const int* perm = nullptr;
+  const bool grouped = gather_grouped(n, k, d_workspace);
+  if (grouped && d_workspace && !getenv("GRT_GATHER_NOSORT")) {
+    rc = gather_sort(pm, d_pos, n, d_workspace, (hipStream_t)stream, &perm);
+    if (rc) return rc;
+  }
+  return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream, grouped, perm);
 } catch (...) {
   return grt_fail_exception("grt_photon_gather_dev");
 }
@@ -1305,19 +1414,21 @@ GRT_API int grt_photon_gather(const grt_pmap* pm, const float* pos, const float*
   DeviceGuard guard;
   GRT_HIP(hipSetDevice(pm->device));
   float *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr;
+  void* d_ws = nullptr;
   const size_t b3 = (size_t)n * 3 * sizeof(float);
   rc = GRT_OK;
   do {
     PTRY(hipMalloc(&d_pos, b3));
     PTRY(hipMalloc(&d_nrm, b3));
     PTRY(hipMalloc(&d_out, b3));
+    PTRY(hipMalloc(&d_ws, grt_photon_gather_workspace_bytes(n)));
     PTRY(hipMemcpy(d_pos, pos, b3, hipMemcpyHostToDevice));
     PTRY(hipMemcpy(d_nrm, nrm, b3, hipMemcpyHostToDevice));
-    rc = gather_launch(pm, d_pos, d_nrm, n, radius, k, d_out, nullptr, nullptr);
+    rc = grt_photon_gather_dev(pm, d_pos, d_nrm, n, radius, k, d_out, d_ws, nullptr);
     if (rc) break;
     PTRY(hipMemcpy(irrad, d_out, b3, hipMemcpyDeviceToHost));
   } while (0);
-  (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out);
+  (void)hipFree(d_pos), (void)hipFree(d_nrm), (void)hipFree(d_out), (void)hipFree(d_ws);
   return rc;
 } catch (...) {
   return grt_fail_exception("grt_photon_gather");
@@ -1342,7 +1453,9 @@ GRT_API uint64_t grt_render_pm_workspace_bytes(const grt_scene* s, const grt_opt
   const int B = pm_batch_of(samples);
   const uint64_t npix = (uint64_t)grt_shard_rows(grt_scene_desc_of(s)->height, shard, n_shards) * (uint64_t)grt_scene_desc_of(s)->width;
   const uint64_t slabs = (grt_accum_workspace_bytes(s, o, shard, n_shards, B) + 255) & ~(uint64_t)255;
-  return slabs + npix * 3 * sizeof(float) + 5 * npix * (uint64_t)B * 3 * sizeof(float) + 1024;
+  const uint64_t nq = npix * (uint64_t)B;
+  const uint64_t sort_ws = (gather_group_enabled() && nq <= 0x7fffffffull) ? ((grt_photon_gather_workspace_bytes((int32_t)nq) + 255) & ~(uint64_t)255) : 0;
+  return slabs + npix * 3 * sizeof(float) + 5 * nq * 3 * sizeof(float) + sort_ws + 1024;
 }
 
 // view == 0: trace() with both maps (scene.go:308-320).  view == 1 / 2: the photon-map view of ONE map (gmap; cmap
@@ -1367,14 +1480,19 @@ static int render_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, 
   float *qnrm = qpos + nq * 3, *qw = qnrm + nq * 3, *irr_g = qw + nq * 3, *irr_c = irr_g + nq * 3;
   hipStream_t st = (hipStream_t)stream;
   if (nq > (size_t)0x7fffffff) return grt_fail(GRT_ELIMIT, "grt_render_accum_pm_dev: %zu gather requests per batch", nq);
+  void* sort_ws = (void*)(((uintptr_t)(irr_c + nq * 3) + 255) & ~(uintptr_t)255);  // Morton sort of the requests (gather_sort)
+  const bool grouped = gather_grouped((int)nq, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, sort_ws);
   for (int s0 = 0, first = 1; s0 < samples; s0 += B, first = 0) {
     const int b = std::min(B, samples - s0);
     GRT_HIP(hipMemsetAsync(qpos, 0xff, nq * 3 * sizeof(float), st));  // all bits set = NaN = no request
     int rc = grt_render_dev_internal(s, o, shard, n_shards, s0, b, frame, base, slab_bytes, d_ray_count, stream, qpos, qnrm, qw, B, view);
     if (rc) return rc;
-    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, irr_g, nullptr, st);  // scene.go:316 | :228 | :262,268
+    const int* perm = nullptr;  // one sort serves both maps: the requests are the same points
+    if (grouped && !getenv("GRT_GATHER_NOSORT")) rc = gather_sort(gmap, qpos, (int)nq, sort_ws, st, &perm);
     if (rc) return rc;
-    if (cmap) rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st);  // scene.go:313
+    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, irr_g, nullptr, st, grouped, perm);  // scene.go:316 | :228 | :262,268
+    if (rc) return rc;
+    if (cmap) rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st, grouped, perm);  // scene.go:313
     if (rc) return rc;
     rc = grt_pm_accumulate_internal(frame, qpos, qw, irr_g, cmap ? irr_c : nullptr, B, npix, d_rgb_sum, first, stream);
     if (rc) return rc;
