@@ -272,3 +272,24 @@ def test_wave_queue_on_a_frame_with_partial_tiles(pkg):
     ren.render()
     torch.cuda.synchronize()
     assert (ren.rgb_sum.cpu().numpy() == q).all() and int(ren.ray_count[0]) == rays_q
+
+
+def test_fixed_point_sums_follow_the_scene_brightness(pkg):
+    """k_pathtrace_bvh adds a pixel's radiance in 64-bit fixed point whose scale comes from a bound on what one path can
+    return (grt_scene_create: brightest source x largest throughput).  Very bright and very dim lights, colours above 1
+    (throughput grows along a path) and a NormalMaterial object (negative radiance, scene.go:275): the frame equals the
+    linear scan's FP32 sums to FP32 rounding in every case — nothing overflows, nothing is rounded away."""
+    T, C = pkg.tracer, pkg._capi
+    cam = pkg.scenes.cornell_camera(96 / 64)
+    rest = pkg.scenes.random_objects(40, 40, 3, diffuse=False)[1:]
+    for emit, colour in ((1e7, (0.73, 0.73, 0.73)), (1e-6, (0.73, 0.73, 0.73)), (15.0, (2.5, 1.5, 3.0))):
+        light = T.NewAABB((213, 548, 227), (343, 548.1, 332), T.LightMaterial(T.NewColor(1, 0.9, 0.8), emit))
+        bright = T.NewSphere((278, 200, 278), 70, T.LambertMaterial(colour))
+        normal = T.NewSphere((150, 100, 150), 60, T.NormalMaterial())
+        objs = [light, bright, normal] + rest
+        bvh = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_BVH)
+        lin = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+        a, b = bvh.RenderAccum(16, seed=9, chunk_spp=16), lin.RenderAccum(16, seed=9, chunk_spp=16)
+        assert np.isfinite(a).all() and np.abs(a).max() > 0 and a.min() < 0          # the NormalMaterial sphere shows negative sums
+        close = np.isclose(a, b, rtol=3e-6, atol=1e-6 * np.abs(b).max())
+        assert close.mean() > 0.998, (emit, colour, close.mean())
