@@ -142,18 +142,20 @@ GRT_DEV void bvh_inner_apply(uint4 c0, uint4 c1, const BvhGrid& G, const RAY& r,
   const bool h0 = bvh_box<CAREFUL>(c0, g, Og, w.H.tbest, tn0);
   const bool h1 = bvh_box<CAREFUL>(c1, g, Og, w.H.tbest, tn1);
   const int r0 = (int)c0.w, r1 = (int)c1.w;
-  if (h0 & h1) {
-    const bool first0 = tn0 <= tn1;
-    *bvh_slot(stack, stride, w.sp) = first0 ? r1 : r0;
-    w.sp++;
-    w.ref = first0 ? r0 : r1;
-  } else if (h0 | h1) {
-    w.ref = h0 ? r0 : r1;
-  } else if (w.sp > 0) {
-    w.ref = *bvh_slot(stack, stride, --w.sp);
-  } else {
-    w.ref = GRT_BVH_DONE;
-  }
+  // Straight-line selects, two exec-masked LDS accesses: the lane masks h0, h1 stay in SGPR pairs (as branches of an
+  // if / else-if chain the compiler turned them into 0/1 VGPRs and compared those again: 8 VALU per node)
+  const bool first0 = tn0 <= tn1;
+  const bool both = h0 & h1, none = !(h0 | h1);
+  const int near = (h0 & (first0 | !h1)) ? r0 : r1;  // the only child hit, or the nearer of two
+  const int far = first0 ? r1 : r0;
+  const bool pop = none & (w.sp > 0);
+  const int top = w.sp - (pop ? 1 : 0);               // entry read (pop) or written (both)
+  int* slot = bvh_slot(stack, stride, top);
+  int next = GRT_BVH_DONE;
+  if (pop) next = *slot;
+  if (both) *slot = far;
+  w.sp = top + (both ? 1 : 0);
+  w.ref = none ? next : near;
 }
 template <bool CAREFUL, class RAY>
 GRT_DEV void bvh_inner_step(const uint4* __restrict__ nodes, const BvhGrid& G, const RAY& r, const BvhRay& g, BvhWalk& w, int* stack,
