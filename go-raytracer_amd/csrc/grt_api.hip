@@ -523,6 +523,10 @@ static int stage(grt_scene* s, DeviceScene& out) {
   for (size_t i = 0; i < nm; ++i) {
     const grt_material& m = s->mats[i];
     int flags = (m.transparent ? GRT_MAT_TRANSPARENT : 0) | (m.lambert ? GRT_MAT_LAMBERT : 0) | (m.normal ? GRT_MAT_NORMAL : 0);
+    const int cls = m.normal ? GRT_CLS_NORMAL : m.emittance > 0 ? GRT_CLS_EMIT : m.lambert ? GRT_CLS_LAMBERT : m.reflectivity > 0 ? GRT_CLS_METAL
+                    : m.transparent ? GRT_CLS_GLASS : GRT_CLS_DIFFUSE;                                       // scene.go:274-305
+    const int vcls = m.reflectivity > 0 ? GRT_CLS_METAL : m.transparent ? GRT_CLS_GLASS : GRT_CLS_DIFFUSE;   // scene.go:207-228
+    flags |= cls << 4 | vcls << 8;
     float w;
     memcpy(&w, &flags, 4);
     hm[GRT_MAT_STRIDE * i] = make_float4((float)m.color[0], (float)m.color[1], (float)m.color[2], (float)m.refr_index);

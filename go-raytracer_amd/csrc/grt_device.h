@@ -103,6 +103,16 @@ struct KScene {
 #define GRT_MAT_TRANSPARENT 1
 #define GRT_MAT_LAMBERT 2
 #define GRT_MAT_NORMAL 4
+// which branch of trace() a material takes (scene.go:274-305), bits 4-6 of the flags word; bits 8-10: of irradiance() (scene.go:207-228)
+#define GRT_CLS_NORMAL 0
+#define GRT_CLS_EMIT 1
+#define GRT_CLS_LAMBERT 2
+#define GRT_CLS_METAL 3
+#define GRT_CLS_GLASS 4
+#define GRT_CLS_DIFFUSE 5
+#define GRT_CLS_MISS 6
+#define GRT_MAT_CLASS(flags) (((flags) >> 4) & 7)
+#define GRT_MAT_VIEW_CLASS(flags) (((flags) >> 8) & 7)
 
 struct Ray32 {
   f3 O, D, invD, OinvD;
@@ -754,14 +764,15 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   const float4 m0 = tm[GRT_MAT_STRIDE * m], m1 = tm[GRT_MAT_STRIDE * m + 1];
   const int flags = __float_as_int(m1.w);
   const f3 color = mk3(m0.x, m0.y, m0.z);
-  // material priority of scene.go:274-305: Normal, Emittance, Lambert, Reflectivity, Transparent, diffuse
-  const bool is_normal = !VIEW & hit & ((flags & GRT_MAT_NORMAL) != 0);
-  const bool is_emit = !VIEW & hit & !is_normal & (m1.z > 0.0f);
-  const bool rest = VIEW ? (hit & (pm->view == 1)) : (hit & !is_normal & !is_emit);
-  const bool is_lamb = !VIEW & rest & ((flags & GRT_MAT_LAMBERT) != 0);
-  const bool is_metal = rest & !is_lamb & (m1.x > 0.0f);                                         // scene.go:207 / :287
-  const bool is_glass = rest & !is_lamb & !is_metal & ((flags & GRT_MAT_TRANSPARENT) != 0);     // scene.go:215 / :295
-  const bool is_diff = VIEW ? (hit & !is_metal & !is_glass) : (rest & !is_lamb & !is_metal & !is_glass);
+  // material priority of scene.go:274-305 — Normal, Emittance, Lambert, Reflectivity, Transparent, diffuse — decided once
+  // per material when the scene is staged (GRT_MAT_CLASS, from the float64 fields); the photon-map view has its own
+  // order (scene.go:207-228: metal, glass, everything else).  One small integer per hit instead of a chain of flags.
+  const int cls = !hit ? GRT_CLS_MISS
+                       : (VIEW ? (pm->view == 1 ? GRT_MAT_VIEW_CLASS(flags) : GRT_CLS_DIFFUSE) : GRT_MAT_CLASS(flags));
+  const bool is_normal = cls == GRT_CLS_NORMAL, is_emit = cls == GRT_CLS_EMIT, is_lamb = cls == GRT_CLS_LAMBERT;
+  const bool is_metal = cls == GRT_CLS_METAL;                                                    // scene.go:207 / :287
+  const bool is_glass = cls == GRT_CLS_GLASS;                                                    // scene.go:215 / :295
+  const bool is_diff = cls == GRT_CLS_DIFFUSE;
   f3 rad = mk3(0.0f, 0.0f, 0.0f);
   if (is_emit) rad = color * m1.z;                                                              // scene.go:279
   if (is_normal) rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);      // scene.go:275
@@ -787,7 +798,7 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
     }
   }
   // a scattering material at the last level: the recursive call returns black (scene.go:238)
-  bool term = !hit | is_normal | is_emit | is_diff | (L.depth + 1 >= S.max_depth);
+  bool term = (cls < GRT_CLS_LAMBERT) | (cls > GRT_CLS_GLASS) | (L.depth + 1 >= S.max_depth);  // miss, Normal, emitter, diffuse
   f3 dir = n;
   if ((is_metal | is_glass) & !term) dir = reflect32(r.D, n);  // metal; glass that reflects (total internal reflection, Schlick)
   if (is_metal & !term) {                           // scene.go:287-294
