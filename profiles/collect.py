@@ -16,7 +16,8 @@ dst = os.path.join(root, "profiles")
 for cfg in ("c2", "c3", "c4", "c4c", "c4pm", "c5"):
     ks = glob.glob(os.path.join(src, f"trace_{cfg}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        lines = open(ks[0]).read().splitlines()[:9]
+        ks.sort(key=os.path.getmtime)   # gpurun merges results into gpurun_out/: an earlier run of the same tag may still lie there
+        lines = open(ks[-1]).read().splitlines()[:9]
         open(os.path.join(dst, f"{name}_{cfg}_kernel_stats.csv"), "w").write("\n".join(lines) + "\n")
     log = os.path.join(src, f"trace_{cfg}.log")
     if os.path.exists(log):
