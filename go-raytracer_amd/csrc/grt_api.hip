@@ -110,6 +110,8 @@ static int validate_scene(const grt_scene_desc* d, const grt_prim* prims, int n_
     return grt_fail(GRT_EINVAL, "grt_scene_create: unknown accel %d", d->accel);
   if (d->accel == GRT_ACCEL_LINEAR && n_prims > GRT_MAX_LINEAR_PRIMS)
     return grt_fail(GRT_ELIMIT, "grt_scene_create: the linear scan takes at most %d objects (got %d)", GRT_MAX_LINEAR_PRIMS, n_prims);
+  // the reference's bias is the constant 0.001 (scene.go:14); the sphere test's three-compare form (sphere_hit32) needs it >= 0
+  if (!(d->bias >= 0.0) || !std::isfinite(d->bias)) return grt_fail(GRT_EINVAL, "grt_scene_create: bias %g; it must be finite and >= 0", d->bias);
   for (int i = 0; i < n_prims; ++i) {
     if (prims[i].kind != GRT_KIND_SPHERE && prims[i].kind != GRT_KIND_AABB)
       return grt_fail(GRT_EINVAL, "grt_scene_create: object %d has unknown kind %d", i, prims[i].kind);
@@ -1226,15 +1228,28 @@ GRT_API int grt_primary_sweep_dev(grt_scene* s, const grt_opts* o, int32_t sampl
   int rc = grt_scene_kernel_view(s, o ? o->seed : 0, &ks);
   if (rc) return rc;
   const int tiles = ((ks.W + 7) / 8) * ((ks.H + 7) / 8);
+  const int variant = o ? (o->flags & 15) : 0;
+  // EYE_OUT of intersect_primary_rel: the eye outside every box (closed) in the float64 scene AND in the FP32 records
+  bool eye_out = true;
+  for (const grt_prim& p : s->prims) {
+    if (p.kind != GRT_KIND_AABB) continue;
+    bool out = false;
+    for (int k = 0; k < 3; ++k) {
+      const double lo = std::min(p.a[k], p.b[k]), hi = std::max(p.a[k], p.b[k]), e = s->d.cam.origin[k];
+      out |= (e < lo && (float)e < (float)lo) || (e > hi && (float)e > (float)hi);
+    }
+    eye_out &= out;
+  }
+  const int mode = (variant == 7 ? 1 : 0) | (variant == 9 ? 2 : 0) | (eye_out ? 4 : 0);
   if (s->use_bvh)
     hipLaunchKernelGGL(k_primary_sweep<-1>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
                        d_checksum, 0);
-  else if (scene_is_small(s) && o && (o->flags & 15) == 3)
+  else if (scene_is_small(s) && variant == 3)
     hipLaunchKernelGGL((k_primary_sweep<GRT_FAST_PRIMS, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        ks, samples, d_checksum, 0);
-  else if (scene_is_small(s) && !(o && (o->flags & 15) == 1))
+  else if (scene_is_small(s) && variant != 1)
     hipLaunchKernelGGL((k_primary_sweep<GRT_FAST_PRIMS, false>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ks, samples, d_checksum, (o && (o->flags & 15) == 7) ? 1 : 0);
+                       ks, samples, d_checksum, mode);
   else
     hipLaunchKernelGGL(k_primary_sweep<0>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ks, samples,
                        d_checksum, 0);

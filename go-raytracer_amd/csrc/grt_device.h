@@ -197,15 +197,19 @@ GRT_DEV float aabb_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, float
   }
 }
 
+// Sphere.Hit (sphere.go:23-46) for tmin >= 0 (grt_scene_create refuses a negative bias).  The reference returns the near root
+// t1 when it lies inside (tMin, tMax), else the far root t2 when that does, and intersect() keeps a result > 0
+// (scene.go:174).  With t1 <= t2 that is: t = t1 > tMin ? t1 : t2, accepted when tMin < t < tMax — if t1 > tMin but
+// t1 >= tMax, t2 >= tMax fails too; t > tMin >= 0 implies the caller's t > 0.  Three compares and one select.
 GRT_DEV float sphere_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, float tmax) {
   f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
-  float k = dot3(oc, r.D) * r.inva;   // halfB / a
-  f3 l = fma3(r.D, -k, oc);           // component of oc perpendicular to D
+  float nk = -dot3(oc, r.D) * r.inva;  // -halfB / a
+  f3 l = fma3(r.D, nk, oc);            // component of oc perpendicular to D
   float s2 = (pb.x - dot3(l, l)) * r.inva;  // disc / a^2
-  float sq = sqrt32(s2);              // NaN when disc < 0: both window tests then fail
-  float t1 = -k - sq, t2 = -k + sq;
-  float t = ((t2 > tmin) & (t2 < tmax)) ? t2 : -1.0f;
-  return ((t1 > tmin) & (t1 < tmax)) ? t1 : t;
+  float sq = sqrt32(s2);              // NaN when disc < 0: every window test then fails
+  float t1 = nk - sq, t2 = nk + sq;
+  const float t = t1 > tmin ? t1 : t2;
+  return ((t > tmin) & (t < tmax)) ? t : -1.0f;
 }
 
 // Scene.intersect (scene.go:169-181): nearest hit over all objects in order, tMax shrinking,
@@ -421,13 +425,12 @@ GRT_DEV void hit_update(float4 pa, float4 pb, bool is_box, int i, const Ray32& r
     best = acc ? i : best;
   } else {
     f3 oc = mk3(r.O.x - pa.x, r.O.y - pa.y, r.O.z - pa.z);
-    float k = dot3(oc, r.D) * r.inva;
-    f3 l = fma3(r.D, -k, oc);
+    float nk = -dot3(oc, r.D) * r.inva;
+    f3 l = fma3(r.D, nk, oc);
     float sq = sqrt32((pb.x - dot3(l, l)) * r.inva);  // NaN when there is no real root
-    float t1 = -k - sq, t2 = -k + sq;
-    const bool in1 = (t1 > bias) & (t1 < tbest), in2 = (t2 > bias) & (t2 < tbest);
-    const float t = in1 ? t1 : t2;
-    const bool acc = (in1 | in2) & (t > 0.0f);
+    float t1 = nk - sq, t2 = nk + sq;
+    const float t = t1 > bias ? t1 : t2;              // sphere_hit32: bias >= 0
+    const bool acc = (t > bias) & (t < tbest);
     tbest = acc ? t : tbest;
     best = acc ? i : best;
   }
@@ -514,40 +517,144 @@ GRT_DEV float vmin3_f32(float a, float b, float c) {
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-GRT_DEV void hit_update_oct(const float* __restrict__ q, bool is_box, int i, const Ray32& r, float bias, float& tbest, int& best) {
+// ---- the object index from the loop's accept masks --------------------------------------------
+// Scene.intersect keeps the LAST object accepted (scene.go:173-178: every accepted object is strictly nearer
+// than the one before).  The unrolled loops below leave one accept mask per object in an SGPR pair; the
+// winner of a lane is the highest i whose mask holds the lane's bit.  Round 2 turned the masks into the index
+// with one v_cndmask per object (9 VALU for 8 objects); here the scalar unit forms, per BIT b of best + 1,
+// the mask of the lanes whose winner has that bit set (W_i = m_i & ~(m_{i+1} | ...), bit_b = OR of the W_i
+// with bit b of i + 1 set) and the lanes shift the bits in with v_addc_co_u32 (v = v + v + carry-in, the
+// carry-in read from an SGPR pair): 4 VALU for 8 objects.  The scalar work runs beside other waves' VALU.
+GRT_DEV uint32_t lane_bit_of(unsigned long long m) {  // 1 in the lanes whose bit of m is set, else 0
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+  return r;
+}
+GRT_DEV uint32_t shift_in_lane_bit(uint32_t v, unsigned long long m) {  // 2 v + (the lane's bit of m)
+  uint32_t r;
+  asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(v), "s"(m) : "vcc");
+  return r;
+}
+GRT_DEV float select_by_mask(float if_clear, float if_set, unsigned long long m) {  // v_cndmask on an SGPR-pair mask
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+template <int NP>
+GRT_DEV int index_from_masks(const unsigned long long (&m)[NP]) {  // best, or -1 when no mask holds the lane
+  constexpr int NB = NP < 2 ? 1 : (NP < 4 ? 2 : (NP < 8 ? 3 : (NP < 16 ? 4 : (NP < 32 ? 5 : 6))));  // bits of NP
+  unsigned long long bit[NB], later = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) bit[b] = 0;
+#pragma unroll
+  for (int i = NP - 1; i >= 0; --i) {
+    const unsigned long long w = m[i] & ~later;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (((i + 1) >> b) & 1) bit[b] |= w;
+    later |= m[i];
+  }
+  uint32_t v = lane_bit_of(bit[NB - 1]);
+#pragma unroll
+  for (int b = NB - 2; b >= 0; --b) v = shift_in_lane_bit(v, bit[b]);
+  return (int)v - 1;
+}
+
+// One object of the loop; returns the accept mask (wave-uniform register pair).
+GRT_DEV unsigned long long hit_update_oct(const float* __restrict__ q, bool is_box, const Ray32& r, float bias, float& tbest) {
+  // (the select and the ballot sit inside each arm: merged behind the scalar branch, the compiler turns the lane
+  // predicate into a 0/1 register and compares it again — two more VALU per object)
   const float4 qa = *(const float4*)q;
   if (is_box) {
     const float2 qb = *(const float2*)(q + 4);
     const float nx = fmaf(qa.x, r.invD.x, -r.OinvD.x), ny = fmaf(qa.y, r.invD.y, -r.OinvD.y), nz = fmaf(qa.z, r.invD.z, -r.OinvD.z);
     const float fx = fmaf(qa.w, r.invD.x, -r.OinvD.x), fy = fmaf(qb.x, r.invD.y, -r.OinvD.y), fz = fmaf(qb.y, r.invD.z, -r.OinvD.z);
-    const float t0 = fmaxf(fmaxf(nx, ny), nz);                    // v_max3
-    const float lo = vmax_f32_s(bias, t0);
+    const float t = fmaxf(fmaxf(nx, ny), nz);                     // v_max3
+    const float lo = vmax_f32_s(bias, t);
     const float hi = vmin3_f32(fx, fy, vmin_f32(fz, tbest));
-    const bool acc = (hi > lo) & (t0 > 0.0f);                     // aabb.go:33-44, scene.go:174
-    tbest = acc ? t0 : tbest;
-    best = acc ? i : best;
+    // aabb.go:33-44, scene.go:174.  The two compare masks are ANDed by the scalar unit and the select reads the SGPR pair
+    // (a ballot of the lane predicate `a & b` costs a v_cndmask 0/1 and a v_cmp_ne more).
+    const unsigned long long acc = __ballot(hi > lo) & __ballot(t > 0.0f);
+    tbest = select_by_mask(tbest, t, acc);
+    return acc;
   } else {
     f3 oc = mk3(r.O.x - qa.x, r.O.y - qa.y, r.O.z - qa.z);
-    float k = dot3(oc, r.D) * r.inva;
-    f3 l = fma3(r.D, -k, oc);
+    float nk = -dot3(oc, r.D) * r.inva;
+    f3 l = fma3(r.D, nk, oc);
     float sq = sqrt32((qa.w - dot3(l, l)) * r.inva);  // NaN when there is no real root
-    float t1 = -k - sq, t2 = -k + sq;
-    const bool in1 = (t1 > bias) & (t1 < tbest), in2 = (t2 > bias) & (t2 < tbest);
-    const float t = in1 ? t1 : t2;
-    const bool acc = (in1 | in2) & (t > 0.0f);
-    tbest = acc ? t : tbest;
-    best = acc ? i : best;
+    float t1 = nk - sq, t2 = nk + sq;
+    const float t = t1 > bias ? t1 : t2;              // sphere_hit32: bias >= 0
+    const unsigned long long acc = __ballot(t > bias) & __ballot(t < tbest);
+    tbest = select_by_mask(tbest, t, acc);
+    return acc;
   }
 }
 // oct: the lane's octant table (oct_tables + ray_octant(D) * GRT_OCT_STRIDE(NP))
 template <int NP>
 GRT_DEV int intersect_lds_oct(const float* __restrict__ oct, uint32_t box_mask, const Ray32& r, float bias, float& t_out) {
   float tbest = 3.402823466e38f;
-  int best = -1;
+  unsigned long long m[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) hit_update_oct(oct + 8 * i, (box_mask >> i) & 1u, i, r, bias, tbest, best);
+  for (int i = 0; i < NP; ++i) m[i] = hit_update_oct(oct + 8 * i, (box_mask >> i) & 1u, r, bias, tbest);
   t_out = tbest;
-  return best;
+  return index_from_masks<NP>(m);
+}
+
+// ---- primary rays: camera-relative tables, one octant per tile ------------------------------------
+// Every primary ray starts at the eye, so (bound - O) of a box and (O - C) of a sphere are constants of the
+// scene: the tables below hold them (differences taken in float64 of the FP32 records, rounded once), a slab
+// distance is ONE multiply, (bound - O) * (1 / D), and a sphere test starts from its oc.  Camera.Ray is affine
+// in (u, v) (camera.go:34-39), so the directions of a tile's rays — every jitter included — are convex
+// combinations of the directions through the tile's four corners: when those agree in the sign of every
+// component (and stay clear of zero), the whole wave reads ONE octant's table at a wave-uniform address and no
+// ray can have a zero component (no per-ray test for the Go NaN path).  EYE_OUT: the eye lies outside every
+// box (closed) — then `t0 > 0` (scene.go:174) follows from `hi > lo`: some axis k has the eye outside the slab;
+// moving towards it, near_k > 0, so t0 > 0; moving away, far_k < 0 <= bias and the window test fails.
+GRT_DEV void octant_record_rel(float4 pa, float4 pb, int oct, f3 O, float* q) {
+  const double ox = (double)O.x, oy = (double)O.y, oz = (double)O.z;
+  if (__float_as_int(pb.w) & 1) {
+    const float lx = fminf(pa.x, pb.x), hx = fmaxf(pa.x, pb.x), ly = fminf(pa.y, pb.y), hy = fmaxf(pa.y, pb.y);
+    const float lz = fminf(pa.z, pb.z), hz = fmaxf(pa.z, pb.z);
+    q[0] = (float)((double)((oct & 1) ? hx : lx) - ox), q[1] = (float)((double)((oct & 2) ? hy : ly) - oy);
+    q[2] = (float)((double)((oct & 4) ? hz : lz) - oz);
+    q[3] = (float)((double)((oct & 1) ? lx : hx) - ox), q[4] = (float)((double)((oct & 2) ? ly : hy) - oy);
+    q[5] = (float)((double)((oct & 4) ? lz : hz) - oz);
+    q[6] = 0.0f, q[7] = 0.0f;
+  } else {
+    q[0] = (float)(ox - (double)pa.x), q[1] = (float)(oy - (double)pa.y), q[2] = (float)(oz - (double)pa.z), q[3] = pb.x;
+    q[4] = 0.0f, q[5] = 0.0f, q[6] = 0.0f, q[7] = 0.0f;
+  }
+}
+// q: ONE octant's camera-relative table, the same address in every lane.  D unnormalised (camera.go:37), t in its units.
+template <int NP, bool EYE_OUT>
+GRT_DEV int intersect_primary_rel(const float* __restrict__ q, uint32_t box_mask, f3 D, f3 invD, float inva, float bias, float& t_out) {
+  float tbest = 3.402823466e38f;
+  unsigned long long m[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float4 qa = *(const float4*)(q + 8 * i);
+    if ((box_mask >> i) & 1u) {
+      const float2 qb = *(const float2*)(q + 8 * i + 4);
+      const float nx = qa.x * invD.x, ny = qa.y * invD.y, nz = qa.z * invD.z;
+      const float fx = qa.w * invD.x, fy = qb.x * invD.y, fz = qb.y * invD.z;
+      const float t = fmaxf(fmaxf(nx, ny), nz);
+      const float lo = vmax_f32_s(bias, t);
+      const float hi = vmin3_f32(fx, fy, vmin_f32(fz, tbest));
+      m[i] = EYE_OUT ? __ballot(hi > lo) : (__ballot(hi > lo) & __ballot(t > 0.0f));
+      tbest = select_by_mask(tbest, t, m[i]);
+    } else {
+      const f3 oc = mk3(qa.x, qa.y, qa.z);
+      const float nk = -dot3(oc, D) * inva;
+      const f3 l = fma3(D, nk, oc);
+      const float sq = sqrt32((qa.w - dot3(l, l)) * inva);
+      const float t1 = nk - sq, t2 = nk + sq;
+      const float t = t1 > bias ? t1 : t2;
+      m[i] = __ballot(t > bias) & __ballot(t < tbest);
+      tbest = select_by_mask(tbest, t, m[i]);
+    }
+  }
+  t_out = tbest;
+  return index_from_masks<NP>(m);
 }
 
 // Surface(p) from an already fetched object record (see surface32).
@@ -698,7 +805,9 @@ GRT_DEV void primary_unit(const KScene& S, float fx, float fy, float u1, float u
 GRT_DEV void lane_begin(const KScene& S, float fx, float fy, uint32_t pix_key, int s, LaneState& L) {
   L.s = s;
   L.pkey = grt_rng_path_key(pix_key, (uint32_t)s);
-  primary_unit(S, fx, fy, grt_rng_draw(L.pkey, GRT_DIM_JITTER_U), grt_rng_draw(L.pkey, GRT_DIM_JITTER_V), L.O, L.D);
+  float ju, jv;
+  grt_rng_draw2(L.pkey, GRT_PAIR_JITTER, &ju, &jv);
+  primary_unit(S, fx, fy, ju, jv, L.O, L.D);
   L.thr = mk3(1.0f, 1.0f, 1.0f);
   L.acc = mk3(0.0f, 0.0f, 0.0f);
   L.depth = 1;
@@ -803,7 +912,9 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   if ((is_metal | is_glass) & !term) dir = reflect32(r.D, n);  // metal; glass that reflects (total internal reflection, Schlick)
   if (is_metal & !term) {                           // scene.go:287-294
     if (m1.y != 0.0f) {
-      f3 fz = sample_hemi32(n, grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 0)), grt_rng_draw(L.pkey, GRT_DIM_HIT(L.depth, 1)));
+      float z1, z2;
+      grt_rng_draw2(L.pkey, GRT_PAIR_HIT(L.depth), &z1, &z2);
+      f3 fz = sample_hemi32(n, z1, z2);
       dir = unit3(fma3(fz, m1.y, dir));             // keep |D| = 1 (direction unchanged)
     }
     // scene.go:291, tested whatever the roughness: no ray and black when the reflected direction does not
@@ -847,8 +958,10 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
       L.thr = mk3(1.0f, 1.0f, 1.0f);
     }
   }
-  const uint32_t base = term ? GRT_DIM_JITTER_U : GRT_DIM_HIT(L.depth, 0);
-  const float u1 = grt_rng_draw(L.pkey, base), u2 = grt_rng_draw(L.pkey, base + 1u);
+  // one hash for the level's two uniforms: pair L.depth — a path that has just ended has depth 0 = GRT_PAIR_JITTER,
+  // a bounce at depth d draws GRT_PAIR_HIT(d) = d
+  float u1, u2;
+  grt_rng_draw2(L.pkey, (uint32_t)L.depth, &u1, &u2);
   if (term) {
     primary_unit(S, fx, fy, u1, u2, L.O, L.D);
   } else {

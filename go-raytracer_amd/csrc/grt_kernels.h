@@ -498,16 +498,15 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
   const bool valid = i < n;
   const size_t j = valid ? i : 0;
   const int y = (int)(j / (size_t)S.W), x = (int)(j - (size_t)y * (size_t)S.W);
-  uint32_t b0 = 1u << 23, b1 = 1u << 23;  // 0.5 * 2^24
+  uint32_t b0 = 1u << 15, b1 = 1u << 15;  // 0.5 * 2^16
   if (jitter_mode == 1) {
-    const grt_key pk = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)j), 0);
-    b0 = grt_rng_bits24(pk, GRT_DIM_JITTER_U);
-    b1 = grt_rng_bits24(pk, GRT_DIM_JITTER_V);
+    const uint32_t h = grt_rng_hash(grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)j), 0), GRT_PAIR_JITTER);
+    b0 = h & 0xffffu, b1 = h >> 16;
   }
   // Rays are generated in float64 exactly as the reference does (scene.go:93-95,
   // camera.go:37) and rounded once to FP32 for the FP32 intersection.
   d3 O64, D64;
-  make_primary64(S64, S.W, S.H, x, y, (double)b0 * (1.0 / 16777216.0), (double)b1 * (1.0 / 16777216.0), O64, D64);
+  make_primary64(S64, S.W, S.H, x, y, (double)b0 * (1.0 / 65536.0), (double)b1 * (1.0 / 65536.0), O64, D64);
   f3 O = mk3((float)O64.x, (float)O64.y, (float)O64.z), D = mk3((float)D64.x, (float)D64.y, (float)D64.z);
   Ray32 r;
   ray_setup(r, O, D);
@@ -595,14 +594,47 @@ __global__ __launch_bounds__(256) void k_primary_hits(KScene S, KScene64 S64, in
 // Config C2, roofline variant: `samples` jittered primary rays per pixel
 // in-kernel, FP32 only, one checksum word per pixel = sum of (id+1).  A wave owns an 8x8
 // tile so its rays are coherent.  NP > 0: objects in LDS, unrolled loop (as k_pathtrace).
+// mode bit 0: min/max slab test instead of the direction-octant tables (A/B, opts.flags variant 7); bit 1: round 2's loop
+// for every tile (per-lane octant, world coordinates; variant 9); bit 2: the eye lies outside every box of the scene
+// (decided on the host in float64: intersect_primary_rel's EYE_OUT).
+// Production path for <= 8 objects (intersect_primary_rel, grt_device.h): the tables hold the objects relative to the
+// eye; a tile whose corner directions agree in every sign reads ONE octant's table at a wave-uniform address; the ray
+// direction is base(pixel) + (horizontal / W) ju + (vertical / H) jv with the 2^-16 of the 16-bit jitters folded into
+// the two vectors (6 FMA); one hash gives both jitters (grt_rng.h).  Tiles crossed by a zero of a direction component
+// (the centre column and row of the image: < 1 % of the tiles) take round 2's loop.
+template <int NP, bool EYE_OUT>
+GRT_DEV uint32_t sweep_tile_rel(const KScene& S, const float* __restrict__ q, uint32_t pix_key, f3 base, int samples) {
+  const float su = (1.0f / 65536.0f) / (float)S.W, sv = (1.0f / 65536.0f) / (float)S.H;
+  const f3 hu = mk3(S.cam.hx * su, S.cam.hy * su, S.cam.hz * su), vv = mk3(S.cam.vx * sv, S.cam.vy * sv, S.cam.vz * sv);
+  uint32_t sum = 0;
+  for (int s = 0; s < samples; ++s) {
+    asm volatile("" ::: "memory");  // re-read the table from LDS each ray (keeps it out of long-lived VGPRs)
+    const uint32_t h = grt_rng_hash(grt_rng_path_key(pix_key, (uint32_t)s), GRT_PAIR_JITTER);
+    const float ju = (float)(h & 0xffffu), jv = (float)(h >> 16);
+    const f3 D = mk3(fmaf(vv.x, jv, fmaf(hu.x, ju, base.x)), fmaf(vv.y, jv, fmaf(hu.y, ju, base.y)), fmaf(vv.z, jv, fmaf(hu.z, ju, base.z)));
+    const f3 invD = mk3(rcp32(D.x), rcp32(D.y), rcp32(D.z));
+    float t;
+    sum += (uint32_t)(intersect_primary_rel<NP, EYE_OUT>(q, S.box_mask, D, invD, rcp32(dot3(D, D)), S.bias, t) + 1);
+  }
+  return sum;
+}
+
 template <int NP, bool PREFETCH = false>
-__global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum, int no_octants) {
+__global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, uint32_t* __restrict__ checksum, int mode) {
   __shared__ float4 lds[NP > 0 ? (2 + GRT_MAT_STRIDE) * NP : 1];
   __shared__ int bvh_stack[NP < 0 ? GRT_BVH_STACK * 256 : 1];
   constexpr bool OCT = NP > 0 && !PREFETCH;
-  __shared__ __attribute__((aligned(16))) float oct_tables[OCT ? 8 * GRT_OCT_STRIDE(NP > 0 ? NP : 1) : 4];
+  constexpr int NPP = NP > 0 ? NP : 1;
+  __shared__ __attribute__((aligned(16))) float oct_tables[OCT ? 8 * GRT_OCT_STRIDE(NPP) : 4];
+  __shared__ __attribute__((aligned(16))) float rel_tables[OCT ? 8 * GRT_OCT_STRIDE(NPP) : 4];
   SceneTables<NP> T;
-  load_tables<NP>(S, lds, T, OCT && !no_octants ? oct_tables : nullptr);
+  const bool rel = OCT && !(mode & 3);
+  if (OCT && rel) {
+    const f3 eye = mk3(S.cam.ox, S.cam.oy, S.cam.oz);
+    for (int i = threadIdx.x; i < 8 * NPP; i += blockDim.x)
+      octant_record_rel(S.prims[2 * (i % NPP)], S.prims[2 * (i % NPP) + 1], i / NPP, eye, rel_tables + (i / NPP) * GRT_OCT_STRIDE(NPP) + 8 * (i % NPP));
+  }
+  load_tables<NP>(S, lds, T, OCT && !(mode & 1) ? oct_tables : nullptr);  // ends with a barrier
   const int lane = threadIdx.x & 63;
   const int tiles_x = (S.W + 7) >> 3, tiles_y = (S.H + 7) >> 3;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -611,11 +643,38 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
   const bool valid = (x < S.W) & (y < S.H);
   const uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
   uint32_t sum = 0;
+  if (OCT && rel) {
+    // the directions through the four corners of the lane's pixel bound every jittered direction of the pixel
+    f3 O, d00, d10, d01, d11;
+    make_primary(S, x, y, 0.0f, 0.0f, O, d00);
+    make_primary(S, x, y, 1.0f, 0.0f, O, d10);
+    make_primary(S, x, y, 0.0f, 1.0f, O, d01);
+    make_primary(S, x, y, 1.0f, 1.0f, O, d11);
+    const f3 mn = mk3(fminf(fminf(d00.x, d10.x), fminf(d01.x, d11.x)), fminf(fminf(d00.y, d10.y), fminf(d01.y, d11.y)),
+                      fminf(fminf(d00.z, d10.z), fminf(d01.z, d11.z)));
+    const f3 mx = mk3(fmaxf(fmaxf(d00.x, d10.x), fmaxf(d01.x, d11.x)), fmaxf(fmaxf(d00.y, d10.y), fmaxf(d01.y, d11.y)),
+                      fmaxf(fmaxf(d00.z, d10.z), fmaxf(d01.z, d11.z)));
+    // clear of zero by far more than the FP32 rounding of a direction (a few 1e-7 of the terms' magnitudes)
+    const f3 mg = mk3(1e-5f * (fabsf(S.cam.lx) + fabsf(S.cam.hx) + fabsf(S.cam.vx)), 1e-5f * (fabsf(S.cam.ly) + fabsf(S.cam.hy) + fabsf(S.cam.vy)),
+                      1e-5f * (fabsf(S.cam.lz) + fabsf(S.cam.hz) + fabsf(S.cam.vz)));
+    const bool clear = ((mn.x > mg.x) | (mx.x < -mg.x)) & ((mn.y > mg.y) | (mx.y < -mg.y)) & ((mn.z > mg.z) | (mx.z < -mg.z));
+    const unsigned long long all = __ballot(true), bx = __ballot(mx.x < 0.0f), by = __ballot(mx.y < 0.0f), bz = __ballot(mx.z < 0.0f);
+    const bool uniform = (__ballot(clear) == all) & ((bx == 0) | (bx == all)) & ((by == 0) | (by == all)) & ((bz == 0) | (bz == all));
+    if (uniform) {  // wave-uniform
+      const int oct = (bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0);
+      const float* q = rel_tables + oct * GRT_OCT_STRIDE(NPP);
+      sum = (mode & 4) ? sweep_tile_rel<NPP, true>(S, q, pix_key, d00, samples) : sweep_tile_rel<NPP, false>(S, q, pix_key, d00, samples);
+      if (valid) checksum[(size_t)y * (size_t)S.W + (size_t)x] = sum;
+      return;
+    }
+  }
   for (int s = 0; s < samples; ++s) {
     if (NP > 0) asm volatile("" ::: "memory");  // re-read the objects from LDS each ray (see path_advance)
     const grt_key pk = grt_rng_path_key(pix_key, (uint32_t)s);
     f3 O, D;
-    make_primary(S, x, y, grt_rng_draw(pk, GRT_DIM_JITTER_U), grt_rng_draw(pk, GRT_DIM_JITTER_V), O, D);
+    float ju, jv;
+    grt_rng_draw2(pk, GRT_PAIR_JITTER, &ju, &jv);
+    make_primary(S, x, y, ju, jv, O, D);
     Ray32 r;
     ray_setup(r, O, D);
     float t;
@@ -624,7 +683,7 @@ __global__ __launch_bounds__(256) void k_primary_sweep(KScene S, int samples, ui
       id = __any(ray_has_zero(r)) ? intersect_bvh_t<true>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256)
                                   : intersect_bvh_t<false>(S.bvh_nodes, S.bvh_prims, S.bvh_grid, r, S.bias, t, bvh_stack + threadIdx.x, 256);
     else if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
-    else if (NP > 0 && T.oct) id = intersect_lds_oct<(NP > 0 ? NP : 1)>(T.oct + ray_octant(r.D) * GRT_OCT_STRIDE(NP > 0 ? NP : 1), S.box_mask, r, S.bias, t);
+    else if (NP > 0 && T.oct) id = intersect_lds_oct<NPP>(T.oct + ray_octant(r.D) * GRT_OCT_STRIDE(NPP), S.box_mask, r, S.bias, t);
     else if (NP > 0) id = intersect_lds<NP, PREFETCH>(T.tp, S.box_mask, r, S.bias, t);
     else id = intersect32_t<false>(S, r, t);
     sum += (uint32_t)(id + 1);

@@ -14,8 +14,8 @@
 //               words agree in pixel_key + sample * C2 and in pixel_key + sample * C4, hence in sample and in
 //               pixel: no two paths of a frame share a key.  (With one 32-bit word, as in round 1, a third of the 2*10^9
 //               paths of a 1080p x 1000 spp frame shared their whole stream with a path of another pixel.)
-//   draw        one mix32 per uniform with word b folded in between its two multiply rounds (one three-input
-//               xor, no extra instruction); 24 random bits -> exactly representable in f32 and f64
+//   hash        one mix32 per PAIR of uniforms with word b folded in between its two multiply rounds (one
+//               three-input xor, no extra instruction); 16 random bits per uniform, exact in f32 and f64
 #pragma once
 #include <stdint.h>
 
@@ -56,20 +56,36 @@ GRT_HD grt_key grt_rng_next_path_key(uint32_t pixel_key, uint32_t next_sample, g
   k.b = cur.b + GRT_RNG_C4;
   return k;
 }
-GRT_HD uint32_t grt_rng_bits24(grt_key key, uint32_t dim) {
-  uint32_t x = key.a + (dim + 1U) * 0x9E3779B9U;
+// One hash serves a PAIR of uniforms (round 3): pair p of a path's stream is hash(key, p), its low 16 bits are the
+// first uniform of the pair (dimension 2p), its high 16 bits the second (dimension 2p + 1).  Every consumer on this
+// path draws its uniforms in pairs — the two pixel jitters (scene.go:93-94), SampleHemisphereNormal's two draws
+// (vec3.go:203-204) — so a trace() level costs one hash instead of two.  For a fixed key the hash is a bijection of
+// 32 bits, so the pairs (u1, u2) are exactly equidistributed on the 2^16 x 2^16 grid.  16 random bits per uniform
+// (round 2: 24): exactly representable in f32 and f64; the grid's bias (2^-17 relative) is far below the 8-bit output.
+GRT_HD uint32_t grt_rng_hash(grt_key key, uint32_t pair) {
+  uint32_t x = key.a + (pair + 1U) * 0x9E3779B9U;
   x ^= x >> 16;
   x *= 0x7feb352dU;
   x ^= (x >> 15) ^ key.b;
   x *= 0x846ca68bU;
   x ^= x >> 16;
-  return x >> 8;
+  return x;
+}
+GRT_HD uint32_t grt_rng_bits16(grt_key key, uint32_t dim) {
+  const uint32_t h = grt_rng_hash(key, dim >> 1);
+  return (dim & 1U) ? h >> 16 : h & 0xffffU;
+}
+// Both uniforms of pair `pair` (dimensions 2 pair, 2 pair + 1) from one hash.
+GRT_HD void grt_rng_draw2(grt_key path_key, uint32_t pair, float* u1, float* u2) {
+  const uint32_t h = grt_rng_hash(path_key, pair);
+  *u1 = (float)(h & 0xffffU) * (1.0f / 65536.0f);
+  *u2 = (float)(h >> 16) * (1.0f / 65536.0f);
 }
 GRT_HD float grt_rng_draw(grt_key path_key, uint32_t dim) {
-  return (float)grt_rng_bits24(path_key, dim) * (1.0f / 16777216.0f);
+  return (float)grt_rng_bits16(path_key, dim) * (1.0f / 65536.0f);
 }
 GRT_HD double grt_rng_draw64(grt_key path_key, uint32_t dim) {
-  return (double)grt_rng_bits24(path_key, dim) * (1.0 / 16777216.0);
+  return (double)grt_rng_bits16(path_key, dim) * (1.0 / 65536.0);
 }
 
 // Dimension layout of one camera path: 0,1 = pixel jitter (scene.go:93-94); the hit at depth
@@ -79,9 +95,14 @@ GRT_HD double grt_rng_draw64(grt_key path_key, uint32_t dim) {
 #define GRT_DIM_JITTER_U 0u
 #define GRT_DIM_JITTER_V 1u
 #define GRT_DIM_HIT(depth, k) (2u + 2u * (uint32_t)((depth)-1) + (uint32_t)(k))
+#define GRT_PAIR_JITTER 0u                       // dimensions 0, 1
+#define GRT_PAIR_HIT(depth) ((uint32_t)(depth))  // dimensions GRT_DIM_HIT(depth, 0), GRT_DIM_HIT(depth, 1)
 
 // Photon walks (scene.go:140-165, 354-424) use pixel = photon index, sample = map id:
 // 0,1 = emission direction; bounce d owns 2+4(d-1)+{0,1} hemisphere, +2 Refract, +3 roulette.
 #define GRT_PDIM_EMIT_U 0u
 #define GRT_PDIM_EMIT_V 1u
 #define GRT_PDIM_HIT(depth, k) (2u + 4u * (uint32_t)((depth)-1) + (uint32_t)(k))
+#define GRT_PPAIR_EMIT 0u
+#define GRT_PPAIR_HEMI(depth) (1u + 2u * (uint32_t)((depth)-1))  // GRT_PDIM_HIT(depth, 0), (depth, 1)
+#define GRT_PPAIR_RR(depth) (2u + 2u * (uint32_t)((depth)-1))    // GRT_PDIM_HIT(depth, 2) Refract, (depth, 3) roulette

@@ -123,14 +123,15 @@ static inline rng_key rng_path_key(uint32_t pixel_key, uint32_t sample) {
   k.b = pixel_key + sample * 0x27D4EB2EU + 0x165667B1U;
   return k;
 }
+/* One hash per PAIR of uniforms: dimensions 2p and 2p + 1 are the low and the high 16 bits of hash(key, p). */
 static inline double rng_draw(rng_key path_key, uint32_t dim) {
-  uint32_t h = path_key.a + (dim + 1U) * 0x9E3779B9U;
+  uint32_t h = path_key.a + ((dim >> 1) + 1U) * 0x9E3779B9U;
   h ^= h >> 16;
   h *= 0x7feb352dU;
   h ^= (h >> 15) ^ path_key.b;
   h *= 0x846ca68bU;
   h ^= h >> 16;
-  return (double)(h >> 8) * (1.0 / 16777216.0);
+  return (double)((dim & 1U) ? h >> 16 : h & 0xffffU) * (1.0 / 65536.0);
 }
 GRTO_API double grto_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
   return rng_draw(rng_path_key(rng_pixel_key(rng_seed32(seed), pixel), sample), dim);

@@ -10,7 +10,7 @@ def test_rng_streams_agree(pkg, ob):
         pix, smp, dim = int(rs.randint(0, 2**31)), int(rs.randint(0, 100000)), int(rs.randint(0, 32))
         a, b = lib.grt_rng_u01(seed, pix, smp, dim), olib.grto_rng_u01(seed, pix, smp, dim)
         assert a == b and 0.0 <= a < 1.0
-        assert (a * 2**24) == int(a * 2**24)  # 24 bits: exact in float32 and float64
+        assert (a * 2**16) == int(a * 2**16)  # 16 bits per uniform (one hash per pair): exact in float32 and float64
 
 
 def test_rng_is_uniform_and_decorrelated(pkg):
@@ -19,8 +19,13 @@ def test_rng_is_uniform_and_decorrelated(pkg):
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
     c = np.corrcoef(u.T)
     assert np.abs(c - np.eye(4)).max() < 0.08
-    # neighbouring pixels / samples do not repeat each other's draws
-    assert len(np.unique(u[:, 0])) > 0.99 * len(u)
+    # neighbouring pixels / samples do not repeat each other's draws: a pair of uniforms is one 32-bit hash (a single
+    # 16-bit uniform repeats among 2000 draws by the birthday bound: 2000^2 / 2^17 = 30 expected)
+    assert len(np.unique(u[:, :2], axis=0)) == len(u) and len(np.unique(u[:, 2:], axis=0)) == len(u)
+    assert len(np.unique(u[:, 0])) > 0.975 * len(u)
+    # the two halves of a hash are as good as two hashes: joint uniformity of (u0, u1) on a 8 x 8 grid
+    cells = np.histogram2d(u[:, 0], u[:, 1], bins=8, range=[[0, 1], [0, 1]])[0]
+    assert cells.min() > 10 and cells.max() < 60          # 31 expected per cell
 
 
 def _mix32(x):
