@@ -7,15 +7,8 @@ before anything touches the GPU (no torch import here): a process that has initi
 be replaced by another program.
 """
 import os
-import socket
 import subprocess
 import sys
-
-
-def free_port():
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def launched_by_torchrun():
@@ -29,6 +22,8 @@ def self_launch(script, argv, gpus):
         return None
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(script)] + list(argv)
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (a port found here with bind(0) and closed again
+    # could be taken by another process before torchrun binds it); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={gpus}", os.path.abspath(script)] + list(argv)
     return subprocess.call(cmd, env=env)
