@@ -84,9 +84,9 @@ def cpu_baseline(pkg, width, height):
     t1 = time.perf_counter()
     c1.RenderAccum(16, seed=1, nthreads=threads)
     dt1 = time.perf_counter() - t1
-    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": share, "worker_threads": threads, "kind": "port",
             "sample": f"cornell8 {width}x{height} at {spp} spp (all rows), float64 C restatement of the Go "
-                      f"reference, {threads} worker threads (NumCPU()+1, scene.go:106), {dt:.2f} s wall",
+                      f"reference, {threads} worker threads on {share} CPUs (NumCPU()+1, scene.go:106), {dt:.2f} s wall",
             "rays_per_s": rays / dt,
             "host": {"cpu_model": model, "os_cpu_count": total, "cpu_share": share, "cpu_share_from": how},
             "c1": {"value": 640 * 640 * 16 / dt1 / 1e6, "unit": "Msamples/s", "seconds": dt1, "rays_per_s": c1.last_ray_count() / dt1,
@@ -117,6 +117,26 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def carried_profile():
+    """Counters that bench.py does not measure itself (HBM bytes, VALU instruction counts: rocprofv3 --pmc passes, profiles/)
+    are CARRIED OVER from profiles/traffic.json.  They are only valid for the build they were taken on: the file records the
+    hash of the kernel sources and the profile tag; when the running build's hash differs, every carried number is dropped
+    (null) and the line says so."""
+    pkg = importlib.import_module("go-raytracer_amd")
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {"carried_from": {"profile": None, "matches_build": False}}
+    prof = json.load(open(tpath))
+    here = pkg._capi.source_hash()
+    ok = prof.get("src_sha16") == here
+    src = {"profile": prof.get("tag"), "profile_src_sha16": prof.get("src_sha16"), "build_src_sha16": here, "matches_build": ok,
+           "file": "profiles/traffic.json"}
+    if not ok:
+        return {"carried_from": src}
+    prof["carried_from"] = src
+    return prof
+
+
 def other_configs():
     """The other measured configurations of SURVEY.md §8d next to the headline one, so that the driver's bench record holds
     them too: C2 (primary-ray sweep), C4 (photon build + k-nearest gather), C5 (10^6 spheres through the hierarchy).  Each is
@@ -132,25 +152,56 @@ def other_configs():
         except Exception as e:  # noqa: BLE001 (a timeout or a parse error of a side leg)
             return {"error": repr(e)[:300]}
 
+    prof = carried_profile()
     res = {}
     d = leg("bench_primary.py")
-    res["c2_primary_sweep_3840x2160"] = d if "error" in d else {
-        "kernel_ms": d["roofline_variant"]["kernel_ms"], "rays_per_s": d["roofline_variant"]["rays_per_s"],
-        "frac_of_fp32_peak": d["roofline_variant"]["frac"], "parity_kernel_ms": d["parity_variant"]["kernel_ms"],
-        "fp64_retest_fraction": d["parity_variant"]["fp64_retest_fraction"]}
-    d = leg("bench_photon.py", "--cpu-queries", "0")
+    if "error" in d:
+        res["c2_primary_sweep_3840x2160"] = d
+    else:
+        rv = d["roofline_variant"]
+        res["c2_primary_sweep_3840x2160"] = {
+            "kernel_ms": rv["kernel_ms"], "rays_per_s": rv["rays_per_s"], "frac_of_fp32_peak": rv["frac"],
+            "roofline": {"bound": "valu_fp32", "kernel": "k_primary_sweep", "achieved": rv["achieved_TFLOPs"], "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": rv["frac"], "flop_per_ray": 224, "traffic": None,
+                         "note": "256 jittered primary rays per pixel in-kernel, 224 flop per ray (SURVEY.md 8d); HIP events, median of "
+                                 "10 back-to-back launches; no HBM traffic in the loop (one 4-byte checksum per pixel)"},
+            "parity_kernel_ms": d["parity_variant"]["kernel_ms"], "fp64_retest_fraction": d["parity_variant"]["fp64_retest_fraction"],
+            "cpu_baseline": d.get("cpu_baseline")}
+    d = leg("bench_photon.py", "--cpu-queries", "20000")
     if "error" in d:
         res["c4_photon_1e6"] = d
     else:
         g = d["gather"]["global_r0"]
+        l2 = prof.get("c4_gather_l2_request_bytes_per_launch")
         res["c4_photon_1e6"] = {"global_gather_ms": g["ms"], "queries_per_s": g["queries_per_s"], "frac_of_8TBps": g["frac_of_8TBps"],
+                                "roofline": {"bound": "hbm", "kernel": "k_gather_knn", "achieved": g["algorithmic_GBps"], "peak": 8000.0,
+                                             "unit": "GB/s", "frac": g["frac_of_8TBps"], "bytes_per_query": 2836,
+                                             "traffic": prof.get("c4_gather_hbm_bytes_per_launch"),
+                                             "l2_request_bytes_per_launch": l2,
+                                             "carried_from": prof.get("carried_from"),
+                                             "note": "SURVEY.md 8d convention: k x 28 + 36 algorithmic bytes per query x queries / launch "
+                                                     "time; the working set lives in L2 / Infinity Cache, what the kernel moves is the L2 "
+                                                     "request bytes"},
                                 "caustic_gather_ms": d["gather"]["caustic_r1"]["ms"],
                                 "build_global_s": d["emission"]["global_s"], "build_caustic_s": d["emission"]["caustic_s"],
-                                "photon_mapped_render_Msamples_per_s": (d.get("photon_mapped_render") or {}).get("Msamples_per_s")}
-    d = leg("bench_spheres.py", "--cpu-spheres", "0")
-    res["c5_spheres_1e6_256spp"] = d if "error" in d else {
-        "frame_s": d["frame_s"], "Msamples_per_s": d["Msamples_per_s"], "rays_per_s": d["rays_per_s"],
-        "inner_nodes_per_ray": d.get("executed_tests", {}).get("inner_nodes_per_ray")}
+                                "build_global_stored_photons_per_s": d["emission"]["global_stored_per_s"],
+                                "photon_mapped_render_Msamples_per_s": (d.get("photon_mapped_render") or {}).get("Msamples_per_s"),
+                                "cpu_baseline": d.get("cpu_baseline")}
+    d = leg("bench_spheres.py", "--cpu-spheres", "10000")
+    if "error" in d:
+        res["c5_spheres_1e6_256spp"] = d
+    else:
+        ex = d.get("executed_tests", {})
+        res["c5_spheres_1e6_256spp"] = {
+            "frame_s": d["frame_s"], "Msamples_per_s": d["Msamples_per_s"], "rays_per_s": d["rays_per_s"],
+            "inner_nodes_per_ray": ex.get("inner_nodes_per_ray"),
+            "roofline": {"bound": "latency", "kernel": "k_pathtrace_bvh", "executed_flop_per_ray": ex.get("flop_per_ray"),
+                         "executed_bytes_per_ray": ex.get("bytes_per_ray"), "executed_TFLOPs": ex.get("executed_TFLOPs"),
+                         "fetched_GBps": ex.get("fetched_GBps"), "frac_of_fp32_peak": (ex.get("executed_TFLOPs") or 0.0) / PEAK_FP32_TFLOPS,
+                         "frac_of_8TBps": (ex.get("fetched_GBps") or 0.0) / 8000.0,
+                         "note": "executed node-box tests (2 x 25 flop, 32 B per node) and object tests (27 flop, 32 B) per ray from the "
+                                 "counting build (SURVEY.md 8d C5); the walk is bound by dependent-fetch latency, neither by HBM nor by VALU"},
+            "cpu_baseline": d.get("cpu_baseline")}
     return res
 
 
@@ -192,7 +243,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # one rank under a launcher (torchrun --nproc-per-node 1) still forms its process group: the RCCL gather, the
+    # reductions of the statistics and the barriers then run exactly as with N ranks (tests/test_gpu_nccl_world1.py)
+    grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -208,7 +262,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -231,7 +285,7 @@ def main():
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     stats = torch.tensor([elapsed, kernel_ms, float(ren.ray_count.item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -249,9 +303,8 @@ def main():
         achieved = rays_per_launch_rank * FLOP_PER_RAY_SHADED / (kernel_ms * 1e-3) / 1e12
         traffic = None
         issue = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (W, H, S, world) == (1920, 1080, 1000, 1):
-            prof = json.load(open(tpath))
+        prof = carried_profile()
+        if (W, H, S, world) == (1920, 1080, 1000, 1):
             traffic = prof.get("k_pathtrace_hbm_bytes_per_launch")
             n_valu = prof.get("k_pathtrace_valu_wave_instructions_per_launch")
             if n_valu:
@@ -283,6 +336,7 @@ def main():
                                   "are black either way and are counted in value; rays_* count executed intersect() calls)"},
             "rays_per_s": rays_per_s,
             "rays_per_sample": rays / samples_total,
+            "build": {"src_sha16": pkg._capi.source_hash()},
             "roofline": {
                 "bound": "valu_fp32",
                 "kernel": "k_pathtrace",
@@ -291,6 +345,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": traffic,
+                "carried_from": prof["carried_from"],   # traffic and valu_issue are PMC numbers of that profile, not of this run
                 "flop_per_ray": FLOP_PER_RAY_SHADED,
                 "achieved_intersection_only": rays_per_launch_rank * FLOP_PER_RAY_INTERSECT / (kernel_ms * 1e-3) / 1e12,
                 "kernel_ms_per_launch": kernel_ms,
@@ -324,8 +379,9 @@ def main():
         if world == 1 and not args.no_extras and not args.no_other_configs:
             out["other_configs"] = other_configs()
         assert frame is not None and tuple(frame.shape) == (H, W, 3)
+        out["process_group"] = {"backend": dist.get_backend(), "world": dist.get_world_size()} if grouped else None
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,6 +13,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrt_hip.so")
 
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources of libgrt_hip.so: names the build a profile was taken on
+    (bench.py prints it; profiles/traffic.json records it, and bench.py drops carried-over counters that belong to
+    another build)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 GRT_KIND_SPHERE = 0
 GRT_KIND_AABB = 1
 GRT_JITTER_CENTER = 0

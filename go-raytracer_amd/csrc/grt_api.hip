@@ -153,16 +153,20 @@ GRT_API int grt_scene_create(const grt_scene_desc* desc, const grt_prim* prims, 
   // counted as >= 1) x the brightest source — an emitter's Color x Emittance (scene.go:279), NormalMaterial's 0.75
   // (:275), or the direct light of the diffuse branch, <= its Color x the sum of the lights' colours (:322-346).
   {
-    double gain = 1.0, source = 0.75, light_sum = 0.0, diffuse = 0.0;
+    double gain = 1.0, source = 0.0, light_sum = 0.0, diffuse = 0.0;
     auto cmax = [](const grt_material& m) { return std::max(std::fabs(m.color[0]), std::max(std::fabs(m.color[1]), std::fabs(m.color[2]))); };
     for (int i : s->lights) light_sum += cmax(s->mats[s->prims[i].material]);
     for (const grt_material& m : s->mats) {
       gain = std::max(gain, cmax(m) * std::max(1.0, std::fabs(m.reflectivity)));
       if (m.emittance > 0) source = std::max(source, cmax(m) * m.emittance);
-      diffuse = std::max(diffuse, cmax(m) * light_sum);
+      if (m.normal) source = std::max(source, 0.75);  // (n + 0.5) * 0.5 with |n| <= 1 (scene.go:275)
+      const bool plain = !m.normal && !(m.emittance > 0) && !m.lambert && !(m.reflectivity > 0) && !m.transparent;
+      if (plain) diffuse = std::max(diffuse, cmax(m) * light_sum);  // only the plain-diffuse branch adds the lights' COLOURS (scene.go:322-346)
     }
     const double bound = std::pow(gain, std::max(1, desc->max_depth)) * std::max(source, diffuse);
-    s->radiance_log2 = std::isfinite(bound) ? (int)std::ceil(std::log2(std::max(bound, 1.0))) : 1024;
+    // log2 of the bound, rounded up; dim scenes give a negative value and a finer fixed-point unit.  A scene that can
+    // return nothing (no light, no Normal material) or a bound that is not finite is marked (INT_MIN / 1024).
+    s->radiance_log2 = !std::isfinite(bound) ? 1024 : (bound > 0.0 ? (int)std::ceil(std::log2(bound)) : INT32_MIN);
   }
   *out = owner.release();
   return GRT_OK;
@@ -717,7 +721,10 @@ static int make_job(const grt_scene* s, const grt_opts* o, int shard, int n_shar
   for (int c = 0; c < j->n_chunks; ++c) longest = std::max(longest, j->chunk_start[c + 1] - j->chunk_start[c]);
   if (s->use_bvh && longest > (1 << 20))
     return grt_fail(GRT_ELIMIT, "a chunk of %d samples is beyond the 2^20 the hierarchy kernel's fixed-point sums are sized for", longest);
-  const int e2 = std::max(-64, std::min(40, 62 - 20 - s->radiance_log2));
+  if (s->use_bvh && s->radiance_log2 == 1024)
+    return grt_fail(GRT_ELIMIT, "the scene's brightest source x largest throughput is not finite: no fixed-point scale for the hierarchy kernel");
+  // a black scene (INT32_MIN) takes any scale; the exponent stays inside double's range (|e2| <= 900: radiance down to 1e-250)
+  const int e2 = s->radiance_log2 == INT32_MIN ? 0 : std::max(-900, std::min(900, 62 - 20 - s->radiance_log2));
   j->acc_scale = std::ldexp(1.0, e2), j->acc_inv = std::ldexp(1.0, -e2);
   return GRT_OK;
 }
@@ -1034,7 +1041,10 @@ static int render_host(grt_scene* s, const grt_opts* o, int samples, float* rgb_
   bool registered = false;
   if (pixels && !getenv("GRT_NO_ZERO_COPY")) {
     (void)hipSetDevice(opts.first_device);
-    if (hipHostRegister(pixels, (size_t)s->d.height * (size_t)pitch, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+    // exactly the bytes Render may touch: the last row ends after its last pixel (scene.go:128 copies bpp * W bytes per row)
+    const size_t bpp_reg = (size_t)pitch / (size_t)s->d.width;
+    const size_t reg_bytes = (size_t)(s->d.height - 1) * (size_t)pitch + (size_t)s->d.width * bpp_reg;
+    if (hipHostRegister(pixels, reg_bytes, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
       registered = true;
       for (int g = 0; g < G && registered; ++g) {
         void* dp = nullptr;

@@ -173,9 +173,14 @@ GRT_DEV float gomin32(float x, float y) {
   return x < y ? x : y;
 }
 
+// CAREFUL is chosen per WAVE (some lane's ray has a zero direction component); the form is chosen per LANE: a lane
+// whose own ray has no zero component takes the usual form inside a careful wave too, so what a lane computes never
+// depends on which other rays share its wave (with 16-bit uniforms a Lambert bounce leaves exactly along the normal —
+// SampleHemisphereNormal at r2 = 0 — once in 65 536 times, and the hierarchy kernel's lanes meet different wave-mates
+// under different scheduling thresholds).
 template <bool CAREFUL>
 GRT_DEV float aabb_hit32(float4 pa, float4 pb, const Ray32& r, float tmin, float tmax) {
-  if (!CAREFUL) {
+  if (!CAREFUL || !ray_has_zero(r)) {
     float x0 = fmaf(pa.x, r.invD.x, -r.OinvD.x), x1 = fmaf(pb.x, r.invD.x, -r.OinvD.x);
     float y0 = fmaf(pa.y, r.invD.y, -r.OinvD.y), y1 = fmaf(pb.y, r.invD.y, -r.OinvD.y);
     float z0 = fmaf(pa.z, r.invD.z, -r.OinvD.z), z1 = fmaf(pb.z, r.invD.z, -r.OinvD.z);

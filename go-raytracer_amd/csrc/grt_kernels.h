@@ -326,9 +326,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
           int me;
           asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(me));
           if (me == p) {
-            sum_x += (long long)((double)cx * J.acc_scale);
-            sum_y += (long long)((double)cy * J.acc_scale);
-            sum_z += (long long)((double)cz * J.acc_scale);
+            // round to nearest (truncation towards zero would bias dim scenes down by half a unit per path)
+            sum_x += __double2ll_rn((double)cx * J.acc_scale);
+            sum_y += __double2ll_rn((double)cy * J.acc_scale);
+            sum_z += __double2ll_rn((double)cz * J.acc_scale);
           }
         }
       }

@@ -52,9 +52,9 @@ def gather_frame(local, height, rank, world, dst=0, group=None, cache=None):
         cache["src"] = torch.as_tensor(frame_row_source(height, world, local.shape[0]), device=local.device)
         cache["stack"] = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         cache["frame"] = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         cache["stack"][0].copy_(local)
-    else:
+    else:  # also with ONE rank when a process group exists (torchrun --nproc-per-node 1): the RCCL path runs as with N ranks
         dist.gather(local, list(cache["stack"].unbind(0)) if rank == dst else None, dst=dst, group=group)
         if rank != dst:
             return None
@@ -140,7 +140,7 @@ class SampleShardRenderer:
 
     def reduce(self, dst=0):
         """Sum of the ranks' frames on rank dst ([H, W, 3] float32), this rank's own buffer elsewhere."""
-        if self.world > 1:
+        if self.world > 1 or dist.is_initialized():
             dist.reduce(self.rgb_sum, dst=dst, op=dist.ReduceOp.SUM)
         return self.rgb_sum
 
@@ -153,7 +153,7 @@ def gather_slices(pos4, pow4, count, rank, world, group=None):
     (rank * slice + the offset grt_photon_emit_dev left in pow4[:, 3])."""
     n_slice = pos4.shape[0]
     cnt = torch.tensor([int(count)], dtype=torch.int64, device=pos4.device)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(cnts, cnt, group=group)
         poss = [torch.empty_like(pos4) for _ in range(world)]

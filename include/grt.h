@@ -108,7 +108,8 @@ typedef struct {
   uint64_t seed;
   int32_t first_device; /* HIP ordinal of the first device to use */
   int32_t n_devices;    /* 0 or 1 = one device; G>1 = interleaved 8-row bands over G devices */
-  int32_t chunk_spp;    /* samples per work item; 0 = library default */
+  int32_t chunk_spp;    /* samples per work item; 0 = library default.  An explicit value must cut the samples into at
+                         * most 63 chunks (ceil(samples / chunk_spp) <= 63: one partial-sum slab per chunk), else GRT_ELIMIT */
   int32_t flags;        /* GRT_FLAG_* */
 } grt_opts;
 
@@ -134,7 +135,8 @@ void grt_scene_destroy(grt_scene* scene);
 /* Replaces the body of Scene.Render (scene.go:79-136): for every pixel, `samples` paths
  * (scene.go:92-97), mean -> Gamma(2) -> Clamp (scene.go:98-99) -> uint8(255.99*c) written
  * as B,G,R at pixels[y*pitch + x*bpp + {0,1,2}], bpp = pitch / width (scene.go:67-74,85).
- * Bytes beyond the third of each pixel are left untouched. */
+ * Bytes beyond the third of each pixel are left untouched.  `pixels` must hold (height - 1) * pitch + width * bpp
+ * bytes (the last row may end after its last pixel, as a Go slice cut to scene.go:128's copies may); pitch >= 3 * width. */
 int grt_render(grt_scene* scene, const grt_opts* opts, uint8_t* pixels, int32_t pitch,
                int32_t samples);
 
@@ -172,6 +174,9 @@ int grt_render_accum_samples_dev(grt_scene* scene, const grt_opts* opts, int32_t
 int grt_render_accum_noalloc_dev(grt_scene* scene, const grt_opts* opts, int32_t shard, int32_t n_shards,
                                  int32_t samples, float* d_rgb_sum, uint64_t* d_ray_count, void* stream);
 int32_t grt_shard_rows(int32_t height, int32_t shard, int32_t n_shards);
+/* Bytes of d_workspace the device entry points above need.  0 means either "none needed" (one chunk) or that the
+ * arguments are invalid (bad shard, samples <= 0, an explicit opts->chunk_spp that makes more than 63 chunks): the
+ * render call with the same arguments then returns the error code and grt_last_error() says which. */
 uint64_t grt_accum_workspace_bytes(const grt_scene* scene, const grt_opts* opts, int32_t shard,
                                    int32_t n_shards, int32_t samples);
 

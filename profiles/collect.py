@@ -13,6 +13,7 @@ tag, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
+c3_out = None
 for cfg in ("c2", "c3", "c4", "c4c", "c4pm", "c5"):
     ks = glob.glob(os.path.join(src, f"trace_{cfg}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
@@ -29,16 +30,29 @@ for cfg in ("c2", "c3", "c4", "c4c", "c4pm", "c5"):
         out = subprocess.run([sys.executable, os.path.join(dst, "summarize_pmc.py"), pm], capture_output=True, text=True, check=True).stdout
         open(os.path.join(dst, f"{name}_{cfg}_pmc.json"), "w").write(out)
         if cfg == "c3":
-            full = json.loads(out)
-            d = next((v for k, v in full.items() if k.startswith("k_pathtrace<8, true, false")), {})
-            if "hbm_write_bytes" in d:
-                # k_pathtrace stores 12 B per pixel per chunk with dword stores (WRITE_SIZE is exact for those)
-                # and reads only the 0.5 KB scene: FETCH_SIZE raw (no wide coalesced reads to correct for)
-                json.dump({"k_pathtrace_hbm_bytes_per_launch": d["hbm_write_bytes"] + d.get("hbm_read_bytes_raw", 0.0),
-                           "read_bytes": d.get("hbm_read_bytes_raw"), "write_bytes": d["hbm_write_bytes"],
-                           "k_pathtrace_valu_wave_instructions_per_launch": d.get("SQ_INSTS_VALU"),
-                           "k_pathtrace_lane_utilisation": (d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
-                                                            if d.get("SQ_ACTIVE_INST_VALU") else None),
-                           "source": f"profiles/{name}_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB units)",
-                           "config": "1920x1080, 1000 spp, 1 GPU"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+            c3_out = out
+if c3_out:
+    out = c3_out
+    full = json.loads(out)
+    d = next((v for k, v in full.items() if k.startswith("k_pathtrace<8, true, false")), {})
+    if "hbm_write_bytes" in d:
+        # k_pathtrace stores 12 B per pixel per chunk with dword stores (WRITE_SIZE is exact for those)
+        # and reads only the 0.5 KB scene: FETCH_SIZE raw (no wide coalesced reads to correct for)
+        bl = os.path.join(dst, f"{name}_c3_bench_under_trace.json")
+        sha = (json.load(open(bl)).get("build") or {}).get("src_sha16") if os.path.exists(bl) else None
+        c4 = {}
+        p4 = os.path.join(dst, f"{name}_c4_pmc.json")
+        if os.path.exists(p4):
+            g = next((v for k, v in json.load(open(p4)).items() if k.startswith("void k_gather_knn") or k.startswith("k_gather_knn")), {})
+            if g.get("TCC_REQ_sum"):
+                c4 = {"c4_gather_l2_request_bytes_per_launch": 128.0 * g["TCC_REQ_sum"],
+                      "c4_gather_hbm_bytes_per_launch": g.get("hbm_read_bytes_raw", 0.0) + g.get("hbm_write_bytes", 0.0)}
+        json.dump({"tag": name, "src_sha16": sha, **c4,
+                   "k_pathtrace_hbm_bytes_per_launch": d["hbm_write_bytes"] + d.get("hbm_read_bytes_raw", 0.0),
+                   "read_bytes": d.get("hbm_read_bytes_raw"), "write_bytes": d["hbm_write_bytes"],
+                   "k_pathtrace_valu_wave_instructions_per_launch": d.get("SQ_INSTS_VALU"),
+                   "k_pathtrace_lane_utilisation": (d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
+                                                    if d.get("SQ_ACTIVE_INST_VALU") else None),
+                   "source": f"profiles/{name}_c3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB units)",
+                   "config": "1920x1080, 1000 spp, 1 GPU"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("collected", sorted(os.listdir(dst)))

@@ -293,3 +293,16 @@ def test_fixed_point_sums_follow_the_scene_brightness(pkg):
         assert np.isfinite(a).all() and np.abs(a).max() > 0 and a.min() < 0          # the NormalMaterial sphere shows negative sums
         close = np.isclose(a, b, rtol=3e-6, atol=1e-6 * np.abs(b).max())
         assert close.mean() > 0.998, (emit, colour, close.mean())
+    # a scene far below 1 with no NormalMaterial in it: the unit follows the scene (it stopped at 2^-40 and
+    # truncated towards zero, 9e-13 absolute, which a 1e-9 light shows as a relative bias)
+    for emit in (1e-9, 3e-20):
+        light = T.NewAABB((213, 548, 227), (343, 548.1, 332), T.LightMaterial(T.NewColor(1, 0.9, 0.8), emit))
+        objs = [light, T.NewSphere((278, 200, 278), 70, T.LambertMaterial((0.73, 0.73, 0.73)))] + rest
+        bvh = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_BVH)
+        lin = T.Scene(96, 64, cam, objs, accel=C.GRT_ACCEL_LINEAR)
+        a, b = bvh.RenderAccum(16, seed=9, chunk_spp=16), lin.RenderAccum(16, seed=9, chunk_spp=16)
+        assert b.max() > 0 and np.isfinite(a).all()
+        lit = b > 1e-3 * b.max()
+        rel = np.abs(a[lit] - b[lit]) / b[lit]
+        assert (rel < 1e-5).mean() > 0.998, (emit, rel.max())
+        assert abs(a.sum() - b.sum()) / b.sum() < 1e-5            # no systematic bias

@@ -97,6 +97,41 @@ def test_c5_full_scene_is_independent_of_scheduling_and_sample_split(pkg, shard,
     assert torch.allclose(total, whole, rtol=1e-5, atol=1e-6)
 
 
+def test_c5_full_scene_at_its_baseline_sample_count(pkg, shard, monkeypatch):
+    """C5 at BASELINE's 256 spp (the sample count the fixed-point pixel sums are sized for): the production frame
+    (wave queue, 64-bit fixed-point sums) is bit-identical under another scheduling setting, equals the lane = pixel
+    kernel (opts.flags = 8: FP32 sums in sample order) to FP32 rounding — a fixed-point overflow or a lost path would
+    show as a gross difference —, and the two kernels trace the same number of rays."""
+    import torch
+
+    W, H, S = 1920, 1080, 256
+    scene = pkg.scenes.spheres(1000000, W, H)
+    ren = shard.SampleShardRenderer(scene, S, 0, 1, seed=1)
+    ren.render()
+    torch.cuda.synchronize()
+    whole, rays = ren.rgb_sum.clone(), int(ren.ray_count[0])
+    assert torch.isfinite(whole).all() and (whole >= 0).all() and whole.max() > 0
+    assert 1.5 < rays / (W * H * S) < 2.5
+    monkeypatch.setenv("GRT_BVH_SHADE_MIN", "48")
+    monkeypatch.setenv("GRT_BVH_INNER_RUN", "2")
+    ren.ray_count.zero_()
+    ren.render()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("GRT_BVH_SHADE_MIN")
+    monkeypatch.delenv("GRT_BVH_INNER_RUN")
+    assert (ren.rgb_sum == whole).all() and int(ren.ray_count[0]) == rays
+    ren.ray_count.zero_()
+    ren.opts.flags = 8
+    ren.render()
+    torch.cuda.synchronize()
+    ren.opts.flags = 0
+    assert int(ren.ray_count[0]) == rays
+    scale = float(whole.max())
+    diff = (ren.rgb_sum - whole).abs()
+    print(f"C5 256 spp: queue vs lane=pixel kernel, max abs diff {float(diff.max()):.3e} at frame max {scale:.3e}")
+    assert torch.allclose(ren.rgb_sum, whole, rtol=5e-5, atol=5e-6 * scale)
+
+
 def test_c4_full_gather_is_independent_of_the_query_order(pkg):
     """C4: 10^6 photons, one query per primary diffuse hit at 1920x1080 (~9*10^5), k = 100.  The estimate of a
     query does not depend on which queries precede it (the carried bound only prunes), k = 50 and k = 100

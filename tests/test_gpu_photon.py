@@ -29,7 +29,8 @@ def test_gather_matches_oracle_on_loaded_photons(pkg, ob):
         close = np.isclose(a, b, rtol=2e-4, atol=1e-9).all(1)
         # FP32 squared distances can order two photons at the k-th place differently from float64:
         # such a query differs by one photon's power (~1/k of the sum)
-        assert close.mean() > 0.99, (radius, k, close.mean())
+        print(f"gather radius {radius} k {k}: {close.mean():.5f} of the queries within 2e-4")
+        assert close.mean() > 0.999, (radius, k, close.mean())   # measured 1.00000 for all six shapes
         scale = np.abs(b).max(1) + 1e-12
         assert (np.abs(a - b).max(1) / scale)[~close].max(initial=0) < 0.5
 
@@ -191,7 +192,7 @@ def test_photon_mapped_trace_matches_oracle(pkg, ob):
     assert (a >= plain - 1e-6).all() and (a - plain).mean() > 0.002      # the photon term adds light
     close = np.isclose(a, b, rtol=5e-3, atol=1e-4).all(-1)
     print(f"photon-mapped: pixels within 5e-3 of the oracle {close.mean():.4f}, mean {a.mean((0,1))} vs {b.mean((0,1))}")
-    assert close.mean() > 0.97                                           # rest: FP32 path divergence at ties, k-th place swaps
+    assert close.mean() > 0.999                                          # measured 1.0000; a miss would be FP32 path divergence at a tie or a k-th place swap
     assert np.allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=5e-3)
     px = np.zeros(H * W * 4, np.uint8)
     scene.RenderPhotonMapped(px, 4 * W, S, seed=4)
@@ -267,7 +268,7 @@ def test_photon_map_view_matches_oracle(pkg, ob, accel):
         assert a.max() > 0 and np.isfinite(a).all()
         close = np.isclose(a, b, rtol=5e-3, atol=1e-4 * b.max()).all(-1)
         print(f"{accel} view mode {mode}: pixels within 5e-3 of the oracle {close.mean():.4f}, mean {a.mean((0, 1))} vs {b.mean((0, 1))}")
-        assert close.mean() > 0.97                          # rest: FP32 path divergence at silhouettes, k-th place swaps
+        assert close.mean() > 0.999                         # measured 1.0000 (linear and hierarchy scenes, both modes)
         assert np.allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=1e-2)
     # the view differs from trace(): the light itself shows the photon estimate (scene.go:225-230 has no Emittance case)
     first = scene.RenderAccumPhotonView(gmap, 2, seed=4, mode=C.GRT_PMVIEW_FIRST_HIT)

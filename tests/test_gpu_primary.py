@@ -123,7 +123,8 @@ def test_primary_sweep_checksum(pkg, ob):
         torch.cuda.synchronize()
         sums.append(chk.cpu().numpy().reshape(360, 640))
     assert (sums[0] == sums[1]).all()
-    assert (sums[0] == rid + 1).mean() > 0.9995
+    print(f"sweep checksum == oracle id + 1 on {(sums[0] == rid + 1).mean():.6f} of the pixels")
+    assert (sums[0] == rid + 1).mean() > 0.9999         # measured 1.000000 (230 400 pixels)
     o = scene.opts(seed=1)
     chk = torch.zeros(640 * 360, dtype=torch.int32, device="cuda")
     pkg._capi.check(lib.grt_primary_sweep_dev(scene.handle, C.byref(o), 64, chk.data_ptr(), None))

@@ -19,8 +19,40 @@ def box(img, k):
 
 
 def linear(img_u8):
-    """Undo WriteColor + Gamma(2): c = (byte / 255.99)^2 (scene.go:68-70,98)."""
-    return (img_u8 / 255.99) ** 2
+    """Undo WriteColor + Gamma(2) (scene.go:68-70,98).  uint8(255.99 c) truncates, so a byte b stands for
+    c in [b, b + 1) / 255.99: the bin centre is the unbiased inverse (taking the lower edge reads every region
+    1-4 % too dark, 0.5 / b in gamma space); 255 is the clamp (c >= 0.996 -> 1 after Clamp())."""
+    g = np.where(img_u8 >= 255, 255.99, np.where(img_u8 <= 0, 0.0, img_u8 + 0.5)) / 255.99
+    return g**2
+
+
+# Regions of images/scene_1000.png (x0, x1, y0, y1; 640 x 640, row 0 on top) that pin what a whole-frame mean cannot:
+# a wrong Schlick term or metal weight changes the spheres and the caustic, a few % of the frame.
+REGIONS = {
+    "red wall": (25, 120, 150, 450), "green wall": (520, 615, 150, 450), "back wall": (180, 460, 180, 380),
+    "ceiling": (150, 490, 25, 50), "floor front": (100, 330, 590, 615), "mirror sphere": (195, 270, 425, 510),
+    "glass sphere": (380, 460, 440, 540), "caustic under the glass sphere": (425, 480, 565, 585), "light": (250, 400, 80, 110),
+}
+
+
+def reference_linear():
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "reference_scene_1000.png")).convert("RGB"), np.float64)
+    assert ref.shape == (640, 640, 3)
+    return linear(ref)
+
+
+def region_errors(mean_linear, rows=None):
+    """Relative difference of the clamped linear means per region and channel against the reference image.
+    rows = (y0, y1): mean_linear holds valid rows only there; regions outside are skipped."""
+    lin = reference_linear()
+    out = {}
+    for name, (x0, x1, y0, y1) in REGIONS.items():
+        if rows is not None and not (rows[0] <= y0 and y1 <= rows[1]):
+            continue
+        a = np.minimum(1.0, mean_linear[y0:y1, x0:x1]).mean((0, 1))
+        b = lin[y0:y1, x0:x1].mean((0, 1))
+        out[name] = (a - b) / b
+    return out
 
 
 def compare_with_reference(mean_linear, k=8):
@@ -41,7 +73,7 @@ def test_oracle_matches_reference_image(pkg, ob):
     psnr, m_or, m_ref, ref = compare_with_reference(mean)
     # measured: 38.8 dB at 24 spp; the residual is Monte Carlo noise of the 24-spp side
     assert psnr > 35.0, psnr
-    assert np.all(np.abs(m_or - m_ref) / m_ref < 0.02), (m_or, m_ref)
+    assert np.all(np.abs(m_or - m_ref) / m_ref < 0.01), (m_or, m_ref)     # measured 0.2 % (bin-centre inverse of the bytes)
     # orientation: red wall on the left, green on the right, light on top
     assert mean[320, 60, 0] > 2 * mean[320, 60, 1] and mean[320, 580, 1] > 1.5 * mean[320, 580, 0]
     assert (mean[90, 320] >= 1).all() and (ref[90, 320] == 255).all()
@@ -51,3 +83,24 @@ def test_oracle_matches_reference_image(pkg, ob):
     assert 0.09 < ref_black.mean() < 0.10
     assert (mean.sum(-1)[ref_black] == 0).mean() > 0.98
     assert (box(mean, 8).sum(-1)[~(box(ref, 8).sum(-1) == 0)] > 0).mean() > 0.99
+
+
+def test_oracle_matches_reference_image_by_region(pkg, ob):
+    """Per-region linear means against the reference's own 1000-spp image: walls, ceiling, floor, both spheres, the
+    caustic patch, the light.  Each band of rows is rendered at a sample count that puts the Monte Carlo error of
+    the region mean below 0.5 % (bounded CPU time); the stated tolerance of 2 % (3 % for channels below 0.02, whose
+    8-bit bins are 2 % wide) covers that, the reference's own noise and its 8-bit quantisation.  Measured: <= 0.9 %."""
+    s = ob.OracleScene(pkg.scenes.cornell_flat(640, 640))
+    worst = 0.0
+    for (y0, y1), spp in (((150, 450), 48), ((25, 50), 400), ((590, 615), 400), ((425, 540), 96), ((565, 585), 400), ((80, 110), 16)):
+        mean = s.RenderAccum(spp, seed=5, row_begin=y0, row_end=y1) / spp
+        errs = region_errors(mean, rows=(y0, y1))
+        assert errs
+        lin = reference_linear()
+        for name, e in errs.items():
+            x0, x1, ry0, ry1 = REGIONS[name]
+            level = lin[ry0:ry1, x0:x1].mean((0, 1))
+            tol = np.where(level < 0.02, 0.03, 0.02)
+            assert (np.abs(e) < tol).all(), (name, e)
+            worst = max(worst, float(np.abs(e).max()))
+    print(f"oracle vs reference PNG, worst regional mean difference {worst:.4f}")

@@ -90,3 +90,33 @@ def test_sizes_beyond_the_scratch(pkg):
     pkg._capi.check(lib.grt_render_accum_noalloc_dev(scene.handle, C.byref(o), 0, 1, 16, frame.data_ptr(), rays.data_ptr(), st))
     torch.cuda.synchronize()
     assert torch.allclose(frame, want, rtol=1e-5, atol=1e-5) and frame.max() > 0
+
+
+def test_no_alloc_entry_point_under_graph_capture(pkg):
+    """include/grt.h names HIP graph capture as a caller: the call is captured on a side stream (an allocation, a
+    synchronisation or a legacy-stream operation inside it would fail the capture), replayed twice, and the replayed
+    frame equals the eager one bit for bit."""
+    import torch
+
+    lib = pkg._capi.load()
+    scene = pkg.scenes.cornell(320, 180)
+    (want, rays_want), _ = both(pkg, scene, 48, 0, 1, 8)            # eager; also stages the scene on the device
+    o = scene.opts(seed=3, chunk_spp=8)
+    frame = torch.zeros((180, 320, 3), dtype=torch.float32, device="cuda")
+    rays = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    rc = None
+    with torch.cuda.graph(graph, stream=side):
+        rc = lib.grt_render_accum_noalloc_dev(scene.handle, C.byref(o), 0, 1, 48, frame.data_ptr(), rays.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.grt_last_error()
+    torch.cuda.synchronize()
+    assert float(frame.abs().max()) == 0.0                         # captured, not run
+    for n in (1, 2):
+        frame.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert (frame == want).all()
+        assert int(rays.item()) == n * rays_want

@@ -87,7 +87,14 @@ if a.cpu_queries > 0:
     t0 = time.perf_counter()
     o.gather(P[sel].astype(np.float64), N[sel].astype(np.float64), 0.0, a.k, nthreads=threads)
     dt = time.perf_counter() - t0
-    cpu = {"queries_per_s": len(sel) / dt, "cores": threads, "kind": "port", "sample": f"{len(sel)} of the {nq} queries, k={a.k}"}
+    cpu = {"queries_per_s": len(sel) / dt, "cores": threads, "kind": "port", "sample": f"{len(sel)} of the {nq} queries, k={a.k}, {dt:.2f} s"}
+    # mapPhotons + ScalePhotonPower (scene.go:140-165, photon_mapping.go:165-209) on the CPU: single-threaded as in the
+    # reference (one goroutine, one rnd), 10^5 stored photons
+    nb = 100000
+    t0 = time.perf_counter()
+    om = ob.OraclePhotonMap.build(ob.OracleScene(scene.flat), nb, caustics=False, seed=1)
+    dtb = time.perf_counter() - t0
+    cpu["build"] = {"stored_photons_per_s": om.count() / dtb, "cores": 1, "sample": f"{om.count()} stored photons ({om.emitted()} emitted) + balanced tree, {dtb:.2f} s"}
 
 pm = None
 if a.render_spp > 0:
@@ -116,4 +123,4 @@ print(json.dumps({
                  "global_stored_per_s": gmap.count() / t_global, "caustic_emitted_per_s": cmap.emitted() / t_caustic,
                  "note": "wall time of grt_photon_build (synchronous): emission + scan/scatter batches, then the device tree build "
                          "(one radix sort per level); photons never leave the device"},
-    "gather": res, "photon_mapped_render": pm, "cpu_baseline": cpu}))
+    "gather": res, "photon_mapped_render": pm, "cpu_baseline": cpu, "build": {"src_sha16": pkg._capi.source_hash()}}))

@@ -22,6 +22,7 @@ ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--samples", type=int, default=256)
 ap.add_argument("--rounds", type=int, default=10)
 ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--cpu", type=int, default=1, help="time the float64 CPU restatement on the same frame (one thread); 0 = skip")
 a = ap.parse_args()
 lib = pkg._capi.load()
 scene = pkg.scenes.cornell(a.width, a.height)
@@ -45,6 +46,18 @@ times = [e0.elapsed_time(e1) for e0, e1 in ev[2:]]
 times.sort()
 ms = times[len(times) // 2]
 rays = a.width * a.height * a.samples
+cpu = None
+if a.cpu:
+    import time
+
+    from oracle import binding as ob
+    ref = ob.OracleScene(scene.flat)
+    t0 = time.perf_counter()
+    rid, _, _ = ref.PrimaryHits()
+    dt = time.perf_counter() - t0
+    cpu = {"value": a.width * a.height / dt, "unit": "rays/s", "cores": 1, "kind": "port",
+           "sample": f"one {a.width}x{a.height} frame of pixel-centre primary rays (Camera.Ray + intersect + Surface), float64 C "
+                     f"restatement, one thread, {dt:.2f} s", "ids_equal_to_hip": bool((rid == ids).all())}
 hit_frac = float((chk > 0).float().mean().item())
 print(json.dumps({
     "workload": f"C2: cornell8 {a.width}x{a.height} aspect 16/9, primary rays only",
@@ -52,4 +65,5 @@ print(json.dumps({
                        "fp64_retest_fraction": fb / (a.width * a.height), "note": "HBM-write/launch bound; no VALU fraction quoted"},
     "roofline_variant": {"samples_per_pixel": a.samples, "kernel_ms": ms, "rays_per_s": rays / ms * 1e3,
                          "kernel_ms_min_max": [times[0], times[-1]], "flop_per_ray": 224, "achieved_TFLOPs": rays * 224 / ms / 1e9, "peak_TFLOPs": 157.3,
-                         "frac": rays * 224 / ms / 1e9 / 157.3, "pixels_with_a_hit": hit_frac}}))
+                         "frac": rays * 224 / ms / 1e9 / 157.3, "pixels_with_a_hit": hit_frac},
+    "cpu_baseline": cpu, "build": {"src_sha16": pkg._capi.source_hash()}}))

@@ -38,7 +38,8 @@ if world != a.gpus:
     raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 dev = torch.device("cuda", torch.cuda.current_device())
-if world > 1:
+grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # one rank under a launcher still forms its group (RCCL path as with N)
+if grouped:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=dev)
@@ -54,7 +55,7 @@ times = []
 for k in range(a.steps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     w0 = time.perf_counter()
     e0.record()
@@ -74,7 +75,7 @@ torch.cuda.synchronize()
 c_rays, c_inner, c_objs = (float(v) for v in ren.ray_count[:3].tolist())
 c_sched = [float(v) for v in ren.ray_count[3:11].tolist()]
 ren.opts.flags = 0
-if world > 1:
+if grouped:
     st = torch.tensor([wall, rays], dtype=torch.float64, device=dev)
     mx = st.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = st.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -103,7 +104,7 @@ if rank == 0:
                                          f"{a.spheres + 2} object tests per ray (scene.go:173)"}
     if a.cpu_spheres > 0 and world == 1:
         from oracle import binding as ob
-        cw, ch, cspp = 640, 360, 8
+        cw, ch, cspp = 320, 180, 8
         threads = importlib.import_module("bench").host_cpu_share()[0] + 1   # NumCPU()+1 workers (scene.go:106)
         o = ob.OracleScene(pkg.scenes.spheres_flat(a.cpu_spheres, cw, ch))
         t0 = time.perf_counter()
@@ -113,7 +114,9 @@ if rank == 0:
                                "sample": f"{a.cpu_spheres} spheres (linear scan as scene.go:173), {cw}x{ch}, {cspp} spp, {dt:.1f} s",
                                "extrapolated_to_scene_Msamples_per_s": cw * ch * cspp / dt / 1e6 * a.cpu_spheres / a.spheres,
                                "note": "the reference's cost is linear in the object count; extrapolation is x N_cpu/N"}
+    out["build"] = {"src_sha16": pkg._capi.source_hash()}
+    out["process_group"] = {"backend": dist.get_backend(), "world": dist.get_world_size()} if grouped else None
     print(json.dumps(out))
-if world > 1:
+if grouped:
     dist.barrier()
     dist.destroy_process_group()
