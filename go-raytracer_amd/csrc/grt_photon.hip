@@ -49,7 +49,7 @@ struct grt_pmap {
   float4* d_boxes = nullptr; // [2 * n_boxes]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
   int* d_order = nullptr;    // [n+1] slot -> storage (emission) index (grt_photon_read)
-  float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};  // bounds of the stored photons (the Morton grid gather queries are sorted on)
+  float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};  // bounds of the stored photons
 };
 
 // ---- emission ---------------------------------------------------------------------------------
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256) void k_kd_upbox(const float4* __restrict__ chi
 }
 
 // d_pos[i] = (x, y, z, bits), d_pow[i] = (r, g, b, -) for the n photons in storage order (device).
+#define GRT_PMAP_MAX_PHOTONS 350000000  // k_gather_knn addresses a photon's 12-byte position with a 32-bit byte offset
 static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, grt_pmap* pm) {
+  if (n > GRT_PMAP_MAX_PHOTONS) return grt_fail(GRT_ELIMIT, "photon map of %d photons; at most %d", n, GRT_PMAP_MAX_PHOTONS);
   int depth = 0;
   while (((long long)KD_LEAF << depth) < n) depth++;
   const int levels = std::max(1, (depth + KD_FAN_BITS - 1) / KD_FAN_BITS);
@@ -378,6 +380,7 @@ static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, gr
   GRT_HIP(hipMalloc(&pm->d_boxes, 2 * total * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_order, ((size_t)n + 1) * sizeof(int)));
   GRT_HIP(hipMemcpy(pm->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+
   GRT_HIP(hipMemset(pm->d_boxes, 0, 2 * total * sizeof(float4)));
   if (n == 0) return GRT_OK;
   unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
@@ -898,24 +901,22 @@ GRT_DEV uint32_t select_kth(const uint32_t (&v)[RMAX], int count, int k, int lan
   return select_kth_bits<RMAX>(mv, j);
 }
 
-// CARRY (round 2): the pool outlives the query.  A walk collects every photon within (estimate of r_k) x (1 + margin)
-// of the query — the ANCHOR — and keeps the positions in LDS; the pool is then the complete ball of radius R around
-// the anchor.  A following query q at distance a from the anchor computes its distances to the pooled photons (no
-// tree walk, no bucket loads), selects the k-th smallest r' among them, and is done when a + min(r', radius) <= R:
-// every photon within its reach is in the pool, so r' IS its k-th distance and the accepted set is exact.  Otherwise
-// the pool is rebuilt around q.  Neighbouring pixels are 0.6 units apart at C4 and r_k is 7: most queries are served
-// from the pool.
-template <int RMAX, int GATHER_WAVES, bool CARRY = false>
+// Work distribution: wave w of the grid serves queries [w q_per_wave, (w + 1) q_per_wave) — consecutive queries are
+// neighbours in image order and hand the carried bound on.  Round 3 measured a device-wide chunk queue instead
+// (resident waves take chunks from an atomic counter until none is left): 1.71 ms against 1.62 for the global map, and
+// 0.82 against 0.53 ms for the caustic map, whose 8-query chunks make 113 000 atomics on one address.  The kernel does
+// not lack resident waves: with 2 / 4 / 6 / 8 waves per SIMD the same launch takes 3.34 / 1.99 / 1.85 / 1.70 ms — it is
+// bound by instruction issue (625 VALU + 621 SALU per query; the CU's scalar unit 58 % busy), DESIGN.md §6.
+template <int RMAX, int GATHER_WAVES>
 __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(80))) void k_gather_knn(KdView T, const float* __restrict__ qpos,
                                                                   const float* __restrict__ qnrm, int n_q, int q_per_wave,
                                                                   float radius, int k, float* __restrict__ irrad,
                                                                   float* __restrict__ rk2_out,
-                                                                  unsigned long long* __restrict__ stats, float loose, float margin) {
+                                                                  unsigned long long* __restrict__ stats, float loose) {
   constexpr int CAP = 64 * RMAX;
   __shared__ float4 top_lo[GATHER_LDS_BOXES], top_hi[GATHER_LDS_BOXES];
   __shared__ float pool_d2[GATHER_WAVES][CAP];
   __shared__ int pool_ix[GATHER_WAVES][CAP];
-  __shared__ float pool_pos[CARRY ? GATHER_WAVES : 1][CARRY ? 3 * CAP : 1];  // CARRY: x[CAP], y[CAP], z[CAP] of the pooled photons
   __shared__ __attribute__((aligned(16))) int hist_all[GATHER_WAVES][GATHER_BINS];
   __shared__ float lut[4 * 256];  // costheta, sintheta, cosphi, sinphi (photon_mapping.go:90-93)
   for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = T.lut[i];
@@ -928,15 +929,12 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
   const int wave = sgpr(threadIdx.x >> 6);
   float* pd2 = pool_d2[wave];
   int* pix = pool_ix[wave];
-  float* ppos = pool_pos[CARRY ? wave : 0];
   int* hist = hist_all[wave];
-  // CARRY: the pool holds every photon within pool_R of (pax, pay, paz); pool_R < 0: no pool
-  float pool_R = -1.0f, pax = 0.0f, pay = 0.0f, paz = 0.0f;
   int count = 0;
-  const int q0 = (blockIdx.x * GATHER_WAVES + wave) * q_per_wave;
-  const int q1 = min(q0 + q_per_wave, n_q);
   const float radius2 = radius * radius;
   const int last = T.levels - 1;
+  const int q0 = (blockIdx.x * GATHER_WAVES + wave) * q_per_wave;
+  const int q1 = min(q0 + q_per_wave, n_q);
   float prev_rk = -1.0f, pqx = 0.0f, pqy = 0.0f, pqz = 0.0f;  // k-th distance of the previous query (if it had one)
 
   float nqx = 0.0f, nqy = 0.0f, nqz = 0.0f;  // the next query's position is requested one query ahead
@@ -965,49 +963,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     uint32_t vb[RMAX];
     int st_nodes = 0, st_leaves = 0, st_sel = 0;  // tuning counters (stats != NULL only)
     uint32_t Tk = 0x7f800000u;  // fewer than k photons: all of them
-    bool served = false;
-    if (CARRY && pool_R >= 0.0f) {  // wave-uniform
-      const float ax = qx - pax, ay = qy - pay, az = qz - paz;
-      const float da = sqrt32(fmaf(az, az, fmaf(ay, ay, ax * ax)));
-      if (da < pool_R) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const int j = lane + 64 * r;
-          vb[r] = 0xffffffffu;
-          if (64 * r < count) {  // wave-uniform
-            const int jj = j < count ? j : 0;
-            const float dx = ppos[jj] - qx, dy = ppos[CAP + jj] - qy, dz = ppos[2 * CAP + jj] - qz;  // same operation order as append_leaf
-            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            if (j < count) vb[r] = __float_as_uint(d2);
-          }
-        }
-        float reach = INFINITY;  // within this distance of the query the estimate needs every photon
-        if (count >= k) {
-          Tk = select_kth<RMAX>(vb, count, k, lane, hist);
-          st_sel++;
-          reach = sqrt32(__uint_as_float(Tk));
-        }
-        if (radius > 0.0f) reach = fminf(reach, radius);
-        served = (da + reach) * 1.00002f <= pool_R;
-        if (!served) Tk = 0x7f800000u;
-      }
-    }
-    if (!served) {
-    if (CARRY) {
-      count = 0;
-      pool_R = -1.0f;
-      // the walk below collects a ball around this query that later queries can be served from: the bound it starts
-      // with (radius, or the carried estimate of r_k) grows by the margin; a bound that is not tight yet (first query
-      // of a wave, a jump) is tightened by the walk itself and the next query rebuilds with the margin
-      if (bound < INFINITY && (tight || radius > 0.0f)) {
-        const float rb = sqrt32(bound) * (1.0f + margin);
-        bound = rb * rb;
-        tight = true;  // collect the whole ball; a pool that overflows is cut down to the k nearest as before
-      }
-    } else {
-      count = 0;
-    }
+    count = 0;
 
     // one step of the walk: the children of node `prefix` at level lvl (boxes off .. ), one per lane
     auto test_group = [&](int lvl, int off, int prefix, float bnd, float& d2box) -> unsigned long long {
@@ -1027,20 +983,22 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     };
     // one leaf bucket: photons within bnd go to the pool
     auto append_leaf = [&](int leaf, float bnd) {
-      const int a = (int)(((long long)leaf * (long long)T.n) >> T.depth);
-      const int b = (int)(((long long)(leaf + 1) * (long long)T.n) >> T.depth);
-      const int i = a + lane;
-      const bool valid = i < b;
-      const P3 p = *(const P3*)(T.pos3 + 3 * (size_t)(valid ? i : a));  // one 12-byte load per lane
+      // bucket [a, b) = [leaf n >> depth, (leaf + 1) n >> depth): unsigned 64-bit products (mul_hi + mul_lo + shift; the
+      // signed form cost 15 scalar instructions per bucket); the lanes beyond the bucket's 33..64 photons as a scalar mask
+      const uint32_t a = (uint32_t)(((unsigned long long)(uint32_t)leaf * (unsigned long long)(uint32_t)T.n) >> T.depth);
+      const uint32_t b = (uint32_t)(((unsigned long long)((uint32_t)leaf + 1u) * (unsigned long long)(uint32_t)T.n) >> T.depth);
+      const uint32_t cnt = b - a;  // <= 64
+      const unsigned long long vmask = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+      const uint32_t i = a + min((uint32_t)lane, cnt - 1u);  // lanes beyond the bucket re-read its last photon
+      // 32-bit byte offset from the scalar base (photon maps hold < 2^31 / 12 photons: checked when the map is built)
+      const P3 p = *(const P3*)((const char*)T.pos3 + 12u * i);  // one 12-byte load per lane
       const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
       const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      const bool pass = valid & (d2 <= bnd);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(d2 <= bnd) & vmask;
       const int slot = count + mbcnt64(m);
-      if (pass) {
+      if ((m >> lane) & 1ull) {
         pd2[slot] = d2;
-        pix[slot] = i;
-        if (CARRY) ppos[slot] = p.x, ppos[CAP + slot] = p.y, ppos[2 * CAP + slot] = p.z;
+        pix[slot] = (int)i;
       }
       count += popc64(m);
       st_leaves++;
@@ -1075,14 +1033,11 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
           const int j = lane + 64 * r;
           const bool keep = vb[r] <= Tk;
           const int ix = pix[j];
-          float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-          if (CARRY) cx = ppos[j], cy = ppos[CAP + j], cz = ppos[2 * CAP + j];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
           const int slot = nc + mbcnt64(m);
           if (keep) {
             pd2[slot] = __uint_as_float(vb[r]);
             pix[slot] = ix;
-            if (CARRY) ppos[slot] = cx, ppos[CAP + slot] = cy, ppos[2 * CAP + slot] = cz;
           }
           nc += popc64(m);
         }
@@ -1169,13 +1124,6 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     // final selection, then the loop of photon_mapping.go:138-161 over the pool
     load_pool();
     if (count >= k) Tk = select_kth<RMAX>(vb, count, k, lane, hist);
-    if (CARRY && T.n > 0 && bound < INFINITY) {
-      // every leaf was tested against a bound >= the final one, and a compaction keeps what lies within the new
-      // bound: the pool is the complete ball of that radius around this query
-      pool_R = sqrt32(bound) * 0.99999f;
-      pax = qx, pay = qy, paz = qz;
-    }
-    }  // !served
     const float nx = qnrm[3 * (size_t)qi], ny = qnrm[3 * (size_t)qi + 1], nz = qnrm[3 * (size_t)qi + 2];
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     uint32_t r2 = 0u;
@@ -1229,138 +1177,52 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
   }
 }
 
-#include "grt_gather_group.h"
-
 #define GRT_GATHER_MAX_K 512
 
-// Workspace of a gather of n queries: the k-th squared distances (n floats, what the caller reads), then the scratch of
-// the Morton sort that puts neighbouring queries into one wave of k_gather_group (keys and query indices, in and out,
-// and hipCUB's temporary storage).
-static bool gather_group_enabled() {  // A/B experiment, off by default (grt_gather_group.h)
-  const char* e = getenv("GRT_GATHER_GROUP");
-  return e && atoi(e) != 0;
-}
-struct GatherWs {
-  float* rk2;
-  uint32_t *k0, *k1;
-  int *v0, *v1;
-  void* tmp;
-  size_t tmp_bytes;
+// Workspace of a gather of n queries: the k-th squared distances (n floats, what the caller reads).
+GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (uint64_t)n * 4 : 0; }
+
+// Tuning knobs (tools/tune_gather.sh), read ONCE when the library first gathers:
+//   GRT_GATHER_QPW    queries served back to back by one wave (they share the carried bound); default 24 for the
+//                     unbounded search, 8 with a radius (queries near the caustic cost far more than the rest)
+//   GRT_GATHER_WAVES  waves per workgroup of the k <= 128 kernel (4, 8, 16)
+//   GRT_GATHER_LOOSE  carried bound / previous r_k^2 above which the bound counts as loose
+//   GRT_GATHER_STATS  per-launch totals on stderr (allocates and synchronises: tuning runs only)
+struct GatherTune {
+  int qpw = 0, waves = 16;
+  float loose = 1.6f;
+  bool stats = false;
+  GatherTune() {
+    if (const char* e = getenv("GRT_GATHER_QPW")) qpw = atoi(e);
+    if (const char* e = getenv("GRT_GATHER_WAVES")) waves = atoi(e);
+    if (const char* e = getenv("GRT_GATHER_LOOSE")) loose = (float)atof(e);
+    stats = getenv("GRT_GATHER_STATS") != nullptr;
+  }
 };
-static uint64_t gather_ws_carve(void* base, int n, GatherWs* w) {
-  auto al = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
-  const uint64_t words = al((uint64_t)n * 4);
-  if (!gather_group_enabled()) {  // the k-th squared distances only
-    if (w) *w = GatherWs{(float*)base, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    return (uint64_t)n * 4;
-  }
-  size_t tmp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int*)nullptr, (int*)nullptr, n, 0, 30);
-  if (w) {
-    char* b = (char*)base;
-    w->rk2 = (float*)b;
-    w->k0 = (uint32_t*)(b + words), w->k1 = (uint32_t*)(b + 2 * words);
-    w->v0 = (int*)(b + 3 * words), w->v1 = (int*)(b + 4 * words);
-    w->tmp = b + 5 * words, w->tmp_bytes = tmp;
-  }
-  return 5 * words + al(tmp);
-}
-GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? gather_ws_carve(nullptr, n, nullptr) : 0; }
-
-GRT_DEV uint32_t morton_spread10(uint32_t v) {  // 10 bits -> every third bit
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-// keys[i] = 30-bit Morton code of query i on a 1024^3 grid over the map's bounds (NaN position = no query: last), vals[i] = i
-__global__ __launch_bounds__(256) void k_gather_keys(const float* __restrict__ qpos, int n, float ox, float oy, float oz, float sx, float sy,
-                                                     float sz, uint32_t* __restrict__ keys, int* __restrict__ vals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float x = qpos[3 * (size_t)i], y = qpos[3 * (size_t)i + 1], z = qpos[3 * (size_t)i + 2];
-  uint32_t key = 0x3fffffffu;
-  if (x == x) {
-    const uint32_t ux = (uint32_t)fminf(fmaxf((x - ox) * sx, 0.0f), 1023.0f), uy = (uint32_t)fminf(fmaxf((y - oy) * sy, 0.0f), 1023.0f),
-                   uz = (uint32_t)fminf(fmaxf((z - oz) * sz, 0.0f), 1023.0f);
-    key = morton_spread10(ux) | (morton_spread10(uy) << 1) | (morton_spread10(uz) << 2);
-  }
-  keys[i] = key;
-  vals[i] = i;
-}
-// Sorts the queries into Morton order: *perm = query index of sorted slot i (in the workspace).
-static int gather_sort(const grt_pmap* pm, const float* d_pos, int n, void* d_workspace, hipStream_t st, const int** perm) {
-  GatherWs w;
-  gather_ws_carve(d_workspace, n, &w);
-  float sc[3];
-  for (int c = 0; c < 3; ++c) {
-    const float ext = pm->bmax[c] - pm->bmin[c];
-    sc[c] = ext > 0.0f ? 1023.99f / ext : 0.0f;
-  }
-  hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_pos, n, pm->bmin[0], pm->bmin[1], pm->bmin[2], sc[0],
-                     sc[1], sc[2], w.k0, w.v0);
-  GRT_HIP(hipGetLastError());
-  GRT_HIP(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, (const uint32_t*)w.k0, w.k1, (const int*)w.v0, w.v1, n, 0, 30, st));
-  *perm = w.v1;
-  return GRT_OK;
-}
-// Which kernel serves a gather: k_gather_knn (one wave per query, the caller's order).  GRT_GATHER_GROUP=1 (an A/B
-// experiment, MEASURED SLOWER: grt_gather_group.h) takes k_gather_group for k <= 128: one group of 64 queries per wave, the
-// queries sorted into Morton order when the caller brought a workspace (which is then larger, see gather_ws_carve).
-static bool gather_grouped(int n, int k, const void* d_workspace) {
-  (void)n, (void)d_workspace;
-  return k <= 128 && gather_group_enabled();
+static const GatherTune& gather_tune() {
+  static const GatherTune t;
+  return t;
 }
 
-// Queries served back to back by one wave of k_gather_knn (they share the carried bound).  GRT_GATHER_QPW
-// overrides the default for tuning runs (tools/bench_photon.py).
-static int gather_qpw(float radius) {
-  const char* e = getenv("GRT_GATHER_QPW");
-  const int v = e ? atoi(e) : 0;
-  // measured at C4: 24 for the unbounded search (longer runs share the carried bound), 8 with a radius
-  // (queries near the caustic cost far more than the rest: shorter runs balance the waves)
-  return v > 0 ? v : (radius > 0.0f ? 8 : 24);
-}
-
-// perm != NULL (or `grouped`): k_gather_group over the queries in the order perm names (NULL: the caller's order).
 static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_nrm, int n, float radius, int k, float* d_irrad,
-                         float* d_rk2, hipStream_t st, bool grouped = false, const int* perm = nullptr) {
-  const int qpw = gather_qpw(radius);
+                         float* d_rk2, hipStream_t st) {
+  const GatherTune& tune = gather_tune();
+  const int qpw = tune.qpw > 0 ? tune.qpw : (radius > 0.0f ? 8 : 24);
   KdView T = {pm->d_boxes, pm->d_pos3, pm->d_pwb, pm->d_lut, pm->n, pm->depth, pm->levels, pm->b0, pm->n_boxes};
-  // GRT_GATHER_STATS=1 (tuning runs only): per-launch totals of node steps, leaf buckets read,
-  // selections and pool sizes on stderr; allocates and synchronises, so never set in production.
   unsigned long long* d_stats = nullptr;
-  if (getenv("GRT_GATHER_STATS")) {
+  if (tune.stats) {
     GRT_HIP(hipMalloc(&d_stats, 16 * sizeof(unsigned long long)));
     GRT_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
   // waves per workgroup by pool size, so that the LDS pools of a CU's 32 waves fit in 160 KB
-#define GRT_GATHER_LAUNCH(RMAX, WAVES, CARRY)                                                                        \
-  hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES, CARRY>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, \
-                     T, d_pos, d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats, loose, margin)
-  const char* lenv = getenv("GRT_GATHER_LOOSE");  // tuning: carried bound / previous r_k^2 above which the bound counts as loose
-  const float loose = lenv ? (float)atof(lenv) : 1.6f;
-  const char* wenv = getenv("GRT_GATHER_WAVES");  // tuning: waves per workgroup of the k <= 128 kernel
-  const int wsel = wenv ? atoi(wenv) : 16;
-  // A/B: 1 = the pool outlives the query (CARRY).  MEASURED SLOWER at C4 (2.39 ms against 1.68 ms at margin 0.15, 2.63 at 0.35):
-  // a served query still pays its distances, its selection and its accumulation (60 % of a query), a rebuild walks a
-  // larger ball, an attempt that cannot be certified pays a selection for nothing, and the positions in LDS halve the
-  // waves per CU.  Exact all the same (tests/test_gpu_photon.py pass with it); kept for the record, off by default.
-  const char* cenv = getenv("GRT_GATHER_CARRY");
-  const bool carry = cenv ? atoi(cenv) != 0 : false;
-  const char* menv = getenv("GRT_GATHER_MARGIN");  // tuning: the pooled ball's radius = (estimate of r_k) x (1 + margin)
-  const float margin = menv ? (float)atof(menv) : 0.45f;
-  const bool group = grouped && k <= 128;
-  if (group) {
-    const unsigned grid = (unsigned)(((n + 63) / 64 + 3) / 4);
-    hipLaunchKernelGGL((k_gather_group<512, 4>), dim3(grid), dim3(256), 0, st, T, d_pos, d_nrm, perm, n, radius, k, d_irrad, d_rk2, d_stats);
-  } else if (k <= 128 && carry) GRT_GATHER_LAUNCH(5, 8, true);
-  else if (k <= 128 && wsel == 4) GRT_GATHER_LAUNCH(5, 4, false);
-  else if (k <= 128 && wsel == 8) GRT_GATHER_LAUNCH(5, 8, false);
-  else if (k <= 128) GRT_GATHER_LAUNCH(5, 16, false);
-  else if (k <= 256) GRT_GATHER_LAUNCH(9, 8, false);
-  else GRT_GATHER_LAUNCH(17, 4, false);
+#define GRT_GATHER_LAUNCH(RMAX, WAVES)                                                                                                  \
+  hipLaunchKernelGGL((k_gather_knn<RMAX, WAVES>), dim3((unsigned)((n + WAVES * qpw - 1) / (WAVES * qpw))), dim3(64 * WAVES), 0, st, T, d_pos, \
+                     d_nrm, n, qpw, radius, k, d_irrad, d_rk2, d_stats, tune.loose)
+  if (k <= 128 && tune.waves == 4) GRT_GATHER_LAUNCH(5, 4);
+  else if (k <= 128 && tune.waves == 8) GRT_GATHER_LAUNCH(5, 8);
+  else if (k <= 128) GRT_GATHER_LAUNCH(5, 16);
+  else if (k <= 256) GRT_GATHER_LAUNCH(9, 8);
+  else GRT_GATHER_LAUNCH(17, 4);
 #undef GRT_GATHER_LAUNCH
   GRT_HIP(hipGetLastError());
   if (d_stats) {
@@ -1368,13 +1230,6 @@ static int gather_launch(const grt_pmap* pm, const float* d_pos, const float* d_
     GRT_HIP(hipStreamSynchronize(st));
     GRT_HIP(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
-    if (k <= 128 && group)
-      fprintf(stderr, "[gather stats] n=%d k=%d radius=%g groups: %.0f per 64 queries, pool %.1f, passes %.2f per group, %.3f splits per 64 queries\n", n,
-              k, (double)radius, (double)h[0] * 64 / n, (double)h[1] / std::max(1.0, (double)h[0]), (double)h[2] / std::max(1.0, (double)h[0]),
-              (double)h[3] * 64 / n);
-    if (group) fprintf(stderr, "   per group: node steps %.1f, leaf buckets %.1f, selections over the pool %.2f\n", h[7] / std::max(1.0, (double)h[0]), h[8] / std::max(1.0, (double)h[0]), h[9] / std::max(1.0, (double)h[0]));
-    if (group) fprintf(stderr, "   mean rho %.2f B %.2f P %.2f per group\n", h[4] * 1e-3 / std::max(1.0, (double)h[0]), h[5] * 1e-3 / std::max(1.0, (double)h[0]), h[6] * 1e-3 / std::max(1.0, (double)h[0]));
-    else
     fprintf(stderr, "[gather stats] n=%d k=%d radius=%g qpw=%d: node steps %.1f, leaf buckets %.2f, selections %.2f, pool %.1f per query\n",
             n, k, (double)radius, qpw, (double)h[0] / n, (double)h[1] / n, (double)h[2] / n, (double)h[3] / n);
   }
@@ -1395,13 +1250,7 @@ GRT_API int grt_photon_gather_dev(const grt_pmap* pm, const float* d_pos, const 
   int rc = gather_check(pm, d_pos, d_nrm, d_irrad, n, k);
   if (rc) return rc;
   if (n == 0) return GRT_OK;
-  const int* perm = nullptr;
-  const bool grouped = gather_grouped(n, k, d_workspace);
-  if (grouped && d_workspace && !getenv("GRT_GATHER_NOSORT")) {
-    rc = gather_sort(pm, d_pos, n, d_workspace, (hipStream_t)stream, &perm);
-    if (rc) return rc;
-  }
-  return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream, grouped, perm);
+  return gather_launch(pm, d_pos, d_nrm, n, radius, k, d_irrad, (float*)d_workspace, (hipStream_t)stream);
 } catch (...) {
   return grt_fail_exception("grt_photon_gather_dev");
 }
@@ -1454,8 +1303,7 @@ GRT_API uint64_t grt_render_pm_workspace_bytes(const grt_scene* s, const grt_opt
   const uint64_t npix = (uint64_t)grt_shard_rows(grt_scene_desc_of(s)->height, shard, n_shards) * (uint64_t)grt_scene_desc_of(s)->width;
   const uint64_t slabs = (grt_accum_workspace_bytes(s, o, shard, n_shards, B) + 255) & ~(uint64_t)255;
   const uint64_t nq = npix * (uint64_t)B;
-  const uint64_t sort_ws = (gather_group_enabled() && nq <= 0x7fffffffull) ? ((grt_photon_gather_workspace_bytes((int32_t)nq) + 255) & ~(uint64_t)255) : 0;
-  return slabs + npix * 3 * sizeof(float) + 5 * nq * 3 * sizeof(float) + sort_ws + 1024;
+  return slabs + npix * 3 * sizeof(float) + 5 * nq * 3 * sizeof(float) + 1024;
 }
 
 // view == 0: trace() with both maps (scene.go:308-320).  view == 1 / 2: the photon-map view of ONE map (gmap; cmap
@@ -1480,19 +1328,14 @@ static int render_pm_dev(grt_scene* s, const grt_opts* o, const grt_pmap* gmap, 
   float *qnrm = qpos + nq * 3, *qw = qnrm + nq * 3, *irr_g = qw + nq * 3, *irr_c = irr_g + nq * 3;
   hipStream_t st = (hipStream_t)stream;
   if (nq > (size_t)0x7fffffff) return grt_fail(GRT_ELIMIT, "grt_render_accum_pm_dev: %zu gather requests per batch", nq);
-  void* sort_ws = (void*)(((uintptr_t)(irr_c + nq * 3) + 255) & ~(uintptr_t)255);  // Morton sort of the requests (gather_sort)
-  const bool grouped = gather_grouped((int)nq, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, sort_ws);
   for (int s0 = 0, first = 1; s0 < samples; s0 += B, first = 0) {
     const int b = std::min(B, samples - s0);
     GRT_HIP(hipMemsetAsync(qpos, 0xff, nq * 3 * sizeof(float), st));  // all bits set = NaN = no request
     int rc = grt_render_dev_internal(s, o, shard, n_shards, s0, b, frame, base, slab_bytes, d_ray_count, stream, qpos, qnrm, qw, B, view);
     if (rc) return rc;
-    const int* perm = nullptr;  // one sort serves both maps: the requests are the same points
-    if (grouped && !getenv("GRT_GATHER_NOSORT")) rc = gather_sort(gmap, qpos, (int)nq, sort_ws, st, &perm);
+    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, irr_g, nullptr, st);  // scene.go:316 | :228 | :262,268
     if (rc) return rc;
-    rc = gather_launch(gmap, qpos, qnrm, (int)nq, 0.0f, view == 2 ? GRT_PMVIEW_DEBUG_K : GRT_PM_K, irr_g, nullptr, st, grouped, perm);  // scene.go:316 | :228 | :262,268
-    if (rc) return rc;
-    if (cmap) rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st, grouped, perm);  // scene.go:313
+    if (cmap) rc = gather_launch(cmap, qpos, qnrm, (int)nq, GRT_PM_CAUSTIC_R, GRT_PM_K, irr_c, nullptr, st);  // scene.go:313
     if (rc) return rc;
     rc = grt_pm_accumulate_internal(frame, qpos, qw, irr_g, cmap ? irr_c : nullptr, B, npix, d_rgb_sum, first, stream);
     if (rc) return rc;
