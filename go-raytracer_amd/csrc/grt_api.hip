@@ -795,10 +795,6 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
     else
       hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   }
-  else if (scene_is_small(s) && variant == 10 && !s->has_diffuse && !pm_pos && ks.max_depth <= 15) {  // levels sorted by material across the workgroup
-    const unsigned gwg = (unsigned)(((int64_t)(j.n_tiles + 3) / 4) * j.n_chunks);
-    hipLaunchKernelGGL((k_pathtrace_wg<GRT_FAST_PRIMS>), dim3(gwg), dim3(256), 0, st, ks, j, target, rcnt);
-  }
   else if (scene_is_small(s) && variant == 4)  // wave queue of (pixel, sample) pairs (92 VGPRs): 45.9 ms vs 44.1 ms
     hipLaunchKernelGGL((k_pathtrace<GRT_FAST_PRIMS, true, false, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
   else if (!scene_is_small(s) && variant != 1 && (int)s->prims.size() <= GRT_LDS_PRIMS && (int)s->mats.size() <= GRT_LDS_PRIMS)

@@ -210,236 +210,6 @@ void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
   }
 }
 
-// ---- k_pathtrace_wg: the levels of trace() sorted by material across a workgroup (round 3) ------------------------------
-// k_pathtrace runs every branch of trace()'s material dispatch in nearly every wave-level: a wave's 64 paths are a mix
-// of fresh primary rays, Lambert bounces and the odd mirror or glass hit, and 28 % of its VALU lanes idle (PMC).  Here a
-// workgroup of 4 waves owns 4 tiles x one chunk of samples as ONE queue of (pixel, sample) pairs (as k_pathtrace_bvh's wave
-// queue, one level up), and between intersect() and the shading of a level the 256 paths are SORTED by what the level
-// will do — end (miss, emitter, depth cap), Lambert, metal, glass, NormalMaterial, no work left — through LDS: a counting
-// sort (ballots, one prefix over the 6 x 4 counts, one 56-byte state record per path).  After the sort a wave holds one
-// or two kinds of path and runs only their code.  A finished path's radiance goes to its pixel's 64-bit fixed-point sum in
-// LDS (exact integer adds: the frame does not depend on the order in which paths end, nor on sharding), and the lane takes
-// the next pair of the workgroup's queue.  The RNG streams are keyed by (pixel, sample): the paths are k_pathtrace's paths.
-// Scenes of <= 8 objects without plain-diffuse objects and without photon maps (the host falls back to k_pathtrace).
-#define WG_KEY_END 0      // miss, emitter, or a scatterer met at the depth cap (scene.go:238): radiance known without Surface()
-#define WG_KEY_LAMBERT 1
-#define WG_KEY_METAL 2
-#define WG_KEY_GLASS 3
-#define WG_KEY_NORMAL 4   // NormalMaterial: ends the path too, but needs the normal
-#define WG_KEY_IDLE 5     // the queue is empty and this lane's last path has ended
-#define WG_KEYS 6
-template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_pathtrace_wg(KScene S, RenderJob J, float* __restrict__ out,
-                                                                                             unsigned long long* __restrict__ ray_count) {
-  __shared__ float4 lds[(2 + GRT_MAT_STRIDE) * NP];
-  __shared__ __attribute__((aligned(16))) float oct_tables[8 * GRT_OCT_STRIDE(NP)];
-  __shared__ float4 x0[256], x1[256], x2[256];  // a path on its way to its sorted slot: (O, t) (D, meta) (thr, sample)
-  __shared__ uint2 x3[256];                     // ... and its RNG key
-  __shared__ unsigned long long sums[3 * 256];  // the 256 pixels' radiance sums, fixed point (J.acc_scale)
-  __shared__ uint32_t pkeys[256];               // their RNG pixel keys
-  __shared__ int cnt[WG_KEYS * 4];              // paths per (key, wave) of this level
-  __shared__ int pre[4][WG_KEYS * 4];           // exclusive prefix of cnt in sorted order, one copy per wave
-  __shared__ int q_next;                        // next pair of the queue
-  __shared__ int live_slot[4], tile_x0[4], tile_y0[4], n_live_s;
-  SceneTables<NP> T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int groups = (J.n_tiles + 3) >> 2;
-  const int grp = blockIdx.x % groups, chunk = blockIdx.x / groups;  // grid = groups * n_chunks
-  const int s0 = J.s_first + J.chunk_start[chunk], s_end = J.s_first + J.chunk_start[chunk + 1];
-  // the pixel this THREAD owns (slot tid of the workgroup's 256): tile grp * 4 + tid / 64
-  const int my_tile = grp * 4 + (tid >> 6);
-  const bool tile_ok = my_tile < J.n_tiles;
-  const int tx = (tile_ok ? my_tile : 0) % J.tiles_x, lband = (tile_ok ? my_tile : 0) / J.tiles_x;
-  const int gband = J.shard + lband * J.n_shards;
-  const int px = tx * 8 + (lane & 7), py = gband * 8 + (lane >> 3), lrow = lband * 8 + (lane >> 3);
-  const bool valid = tile_ok & (px < S.W) & (py < S.H);
-  pkeys[tid] = grt_rng_pixel_key(S.seed32, (uint32_t)py * (uint32_t)S.W + (uint32_t)px);
-  sums[tid] = 0ull, sums[256 + tid] = 0ull, sums[512 + tid] = 0ull;
-  if (lane == 0) tile_x0[wave] = tx * 8, tile_y0[wave] = gband * 8;
-  if (wave == 0) {  // the tiles that are traced at all (inside the frame's tile grid, not culled), compacted
-    const int t = grp * 4 + (lane & 3);
-    const bool okt = t < J.n_tiles;
-    const int ttx = (okt ? t : 0) % J.tiles_x, tb = J.shard + ((okt ? t : 0) / J.tiles_x) * J.n_shards;
-    const bool live = (lane < 4) & okt & (!S.tile_live || S.tile_live[tb * J.tiles_x + ttx]) & (s0 < s_end);
-    const unsigned long long m = __ballot(live);
-    if (live) live_slot[__builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)] = lane;
-    if (lane == 0) n_live_s = __builtin_popcountll(m), q_next = 256;
-  }
-  load_tables<NP>(S, lds, T, oct_tables);  // ends with a barrier
-  const int n_live = __builtin_amdgcn_readfirstlane(n_live_s);
-  const int qend = 64 * n_live * (s_end - s0);
-  const int sh = n_live == 2 ? 1 : (n_live == 4 ? 2 : 0);
-
-  f3 O = mk3(0.0f, 0.0f, 0.0f), D = mk3(0.0f, 0.0f, 1.0f), thr = mk3(1.0f, 1.0f, 1.0f);
-  grt_key pkey = {0u, 0u};
-  int depth = 1, smp = 0, pix = 0, n_rays = 0;
-  bool alive = false, ghost = false;
-  // pair q of the queue: lane pixel q % 64 of live tile (q / 64) % n_live, sample s0 + (q / 64) / n_live
-  auto birth = [&](int q) {
-    const uint32_t g = (uint32_t)q >> 6;
-    const uint32_t so = n_live == 3 ? __umulhi(g, 0x55555556u) : (g >> sh);
-    const int slot = live_slot[g - so * (uint32_t)n_live];
-    pix = slot * 64 + (q & 63);
-    smp = s0 + (int)so;
-    const int x = tile_x0[slot] + (q & 7), y = tile_y0[slot] + ((q >> 3) & 7);
-    ghost = !((x < S.W) & (y < S.H));  // a pixel of an edge tile outside the frame: its pairs end at once, uncounted
-    pkey = grt_rng_path_key(pkeys[pix], (uint32_t)smp);
-    float ju, jv;
-    grt_rng_draw2(pkey, GRT_PAIR_JITTER, &ju, &jv);
-    primary_unit(S, (float)x, (float)y, ju, jv, O, D);
-    thr = mk3(1.0f, 1.0f, 1.0f);
-    depth = 1;
-  };
-  if (tid < qend) alive = true, birth(tid);
-
-  for (;;) {
-    // ---- scene.go:242 for every path of the workgroup
-    int id = -1;
-    float t = 0.0f;
-    if (alive) {
-      Ray32 r;
-      ray_setup_unit(r, O, D);
-      if (__builtin_expect(__any(ray_has_zero(r)), 0)) id = intersect32_t<true>(S, r, t);
-      else id = intersect_lds_oct<NP>(oct_tables + ray_octant(D) * GRT_OCT_STRIDE(NP), S.box_mask, r, S.bias, t);
-      n_rays += ghost ? 0 : 1;
-    }
-    // ---- what this level will do (scene.go:244-305)
-    int key = WG_KEY_IDLE;
-    if (alive) {
-      key = WG_KEY_END;
-      if (ghost) id = -1;
-      if (id >= 0) {
-        const int flags = __float_as_int(T.tm[GRT_MAT_STRIDE * (__float_as_int(T.tp[2 * id + 1].w) >> 8) + 1].w);
-        const int cls = GRT_MAT_CLASS(flags);
-        if (cls == GRT_CLS_NORMAL) key = WG_KEY_NORMAL;
-        else if (cls >= GRT_CLS_LAMBERT && cls <= GRT_CLS_GLASS) {
-          if (depth + 1 < S.max_depth) key = cls - GRT_CLS_LAMBERT + WG_KEY_LAMBERT;
-          else id = -1;  // the recursive call would return black (scene.go:238)
-        } else if (cls != GRT_CLS_EMIT) id = -1;  // (plain diffuse: the host sends such scenes to k_pathtrace)
-      }
-    }
-    // ---- counting sort of the 256 paths by key
-    unsigned long long m[WG_KEYS];
-    int rank = 0;
-#pragma unroll
-    for (int k = 0; k < WG_KEYS; ++k) {
-      m[k] = __ballot(key == k);
-      const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], 0));
-      rank = key == k ? r : rank;
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < WG_KEYS; ++k) cnt[k * 4 + wave] = __builtin_popcountll(m[k]);
-    }
-    __syncthreads();
-    {
-      const int c = lane < WG_KEYS * 4 ? cnt[lane] : 0;
-      int inc = c;
-      inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);  // row_shr 1, 2, 4, 8: 16 entries
-      inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
-      inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);
-      inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);
-      inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);  // row_bcast15: rows 1, 3 += row 0's / 2's total
-      if (lane < WG_KEYS * 4) pre[wave][lane] = inc - c;
-      // every wave sees the same counts: all 256 lanes idle = the workgroup is done
-      const int idle = cnt[WG_KEY_IDLE * 4] + cnt[WG_KEY_IDLE * 4 + 1] + cnt[WG_KEY_IDLE * 4 + 2] + cnt[WG_KEY_IDLE * 4 + 3];
-      if (__builtin_amdgcn_readfirstlane(idle) == 256) break;
-    }
-    {
-      const int dest = pre[wave][key * 4 + wave] + rank;
-      const uint32_t meta = (uint32_t)(id + 1) | ((uint32_t)depth << 4) | ((uint32_t)key << 8) | ((uint32_t)pix << 12) | ((uint32_t)ghost << 20);
-      x0[dest] = make_float4(O.x, O.y, O.z, t);
-      x1[dest] = make_float4(D.x, D.y, D.z, __uint_as_float(meta));
-      x2[dest] = make_float4(thr.x, thr.y, thr.z, __int_as_float(smp));
-      x3[dest] = make_uint2(pkey.a, pkey.b);
-    }
-    __syncthreads();
-    {
-      const float4 a = x0[tid], b = x1[tid], c = x2[tid];
-      const uint2 d = x3[tid];
-      O = mk3(a.x, a.y, a.z), t = a.w, D = mk3(b.x, b.y, b.z), thr = mk3(c.x, c.y, c.z), smp = __float_as_int(c.w);
-      pkey.a = d.x, pkey.b = d.y;
-      const uint32_t meta = __float_as_uint(b.w);
-      id = (int)(meta & 15u) - 1, depth = (int)((meta >> 4) & 15u), key = (int)((meta >> 8) & 15u), pix = (int)((meta >> 12) & 255u);
-      ghost = (meta >> 20) & 1u;
-    }
-    alive = key != WG_KEY_IDLE;
-    // ---- the level's shading, one kind of path (or two) per wave
-    bool term = false;
-    f3 rad = mk3(0.0f, 0.0f, 0.0f);
-    if (key == WG_KEY_END) {
-      term = true;
-      if (id >= 0) {  // an emitter: Color x Emittance, whatever the direction (scene.go:279)
-        const int mi = __float_as_int(T.tp[2 * id + 1].w) >> 8;
-        const float4 m0 = T.tm[GRT_MAT_STRIDE * mi], m1 = T.tm[GRT_MAT_STRIDE * mi + 1];
-        rad = mk3(m0.x * m1.z, m0.y * m1.z, m0.z * m1.z);
-      }
-    } else if (alive) {
-      Ray32 r;
-      ray_setup_unit(r, O, D);
-      f3 p, n;
-      const float4 pa = T.tp[2 * id], pb = T.tp[2 * id + 1];
-      const int mi = surface_rec_oct(pa, pb, oct_tables + ray_octant(D) * GRT_OCT_STRIDE(NP) + 8 * id, r, t, p, n);  // scene.go:254-255
-      const float4 m0 = T.tm[GRT_MAT_STRIDE * mi];
-      const f3 color = mk3(m0.x, m0.y, m0.z);
-      if (key == WG_KEY_NORMAL) {
-        term = true;
-        rad = mk3((n.x + 0.5f) * 0.5f, (n.y + 0.5f) * 0.5f, (n.z + 0.5f) * 0.5f);  // scene.go:275
-      } else if (key == WG_KEY_LAMBERT) {  // scene.go:280-286
-        float u1, u2;
-        grt_rng_draw2(pkey, GRT_PAIR_HIT(depth), &u1, &u2);
-        O = p, D = sample_hemi32(n, u1, u2), thr = thr * color;
-      } else if (key == WG_KEY_METAL) {  // scene.go:287-294
-        const float4 m1 = T.tm[GRT_MAT_STRIDE * mi + 1];
-        f3 dir = reflect32(D, n);
-        if (m1.y != 0.0f) {
-          float z1, z2;
-          grt_rng_draw2(pkey, GRT_PAIR_HIT(depth), &z1, &z2);
-          dir = unit3(fma3(sample_hemi32(n, z1, z2), m1.y, dir));
-        }
-        if (!(dot3(dir, n) > 0.0f)) term = true;  // scene.go:291: black
-        O = p, D = dir, thr = thr * (color * m1.x);
-      } else {  // glass, scene.go:295-304: the pair's first uniform is Refract's roulette draw
-        float u1, u2;
-        grt_rng_draw2(pkey, GRT_PAIR_HIT(depth), &u1, &u2);
-        f3 d;
-        if (!refract32(D, n, T.tm[GRT_MAT_STRIDE * mi + 2], u1, d)) d = reflect32(D, n);
-        O = p, D = d;
-      }
-      depth++;
-    }
-    // ---- a finished path: its radiance to its pixel (scene.go:96), the next pair of the queue to the lane
-    const f3 c = thr * rad;
-    if (term & ((c.x != 0.0f) | (c.y != 0.0f) | (c.z != 0.0f))) {
-      atomicAdd(&sums[pix], (unsigned long long)__double2ll_rn((double)c.x * J.acc_scale));
-      atomicAdd(&sums[256 + pix], (unsigned long long)__double2ll_rn((double)c.y * J.acc_scale));
-      atomicAdd(&sums[512 + pix], (unsigned long long)__double2ll_rn((double)c.z * J.acc_scale));
-    }
-    const unsigned long long ended = __ballot(term);
-    if (ended) {  // wave-uniform
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&q_next, __builtin_popcountll(ended));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (term) {
-        const int q = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ended >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ended, 0));
-        alive = q < qend;
-        if (alive) birth(q);
-      }
-    }
-  }
-  __syncthreads();  // (the atomics of the last level)
-  if (valid) {
-    float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)px) * 3;
-    o[0] = (float)((double)(long long)sums[tid] * J.acc_inv);
-    o[1] = (float)((double)(long long)sums[256 + tid] * J.acc_inv);
-    o[2] = (float)((double)(long long)sums[512 + tid] * J.acc_inv);
-  }
-  if (ray_count) {
-    unsigned long long tot = wave_sum_u32((unsigned)n_rays);
-    if (lane == 0) atomicAdd(ray_count, tot);
-  }
-}
-
 // k_pathtrace for hierarchy scenes (grt_bvh.h).  Same work items (one wave = one 8x8 tile x one
 // chunk of samples, one lane = one pixel) and the same per-sample RNG streams, but the level is
 // not run in lockstep: walks differ a lot in length (C5: 20 % of the lanes were active when every
