@@ -178,6 +178,8 @@ def other_configs():
                                              "unit": "GB/s", "frac": g["frac_of_8TBps"], "bytes_per_query": 2836,
                                              "traffic": prof.get("c4_gather_hbm_bytes_per_launch"),
                                              "l2_request_bytes_per_launch": l2,
+                                             "l2_GBps": (l2 / (g["ms"] * 1e-3) / 1e9) if l2 else None,
+                                             "l2_frac_of_gather_rate": (l2 / (g["ms"] * 1e-3) / 1e9 / 16800.0) if l2 else None,
                                              "carried_from": prof.get("carried_from"),
                                              "note": "SURVEY.md 8d convention: k x 28 + 36 algorithmic bytes per query x queries / launch "
                                                      "time; the working set lives in L2 / Infinity Cache, what the kernel moves is the L2 "
@@ -195,12 +197,18 @@ def other_configs():
         res["c5_spheres_1e6_256spp"] = {
             "frame_s": d["frame_s"], "Msamples_per_s": d["Msamples_per_s"], "rays_per_s": d["rays_per_s"],
             "inner_nodes_per_ray": ex.get("inner_nodes_per_ray"),
-            "roofline": {"bound": "latency", "kernel": "k_pathtrace_bvh", "executed_flop_per_ray": ex.get("flop_per_ray"),
-                         "executed_bytes_per_ray": ex.get("bytes_per_ray"), "executed_TFLOPs": ex.get("executed_TFLOPs"),
-                         "fetched_GBps": ex.get("fetched_GBps"), "frac_of_fp32_peak": (ex.get("executed_TFLOPs") or 0.0) / PEAK_FP32_TFLOPS,
-                         "frac_of_8TBps": (ex.get("fetched_GBps") or 0.0) / 8000.0,
-                         "note": "executed node-box tests (2 x 25 flop, 32 B per node) and object tests (27 flop, 32 B) per ray from the "
-                                 "counting build (SURVEY.md 8d C5); the walk is bound by dependent-fetch latency, neither by HBM nor by VALU"},
+            # what bounds the walk: 128-byte lines from L2 for 32-byte nodes.  The line rate is a PMC number (TCC_REQ x 128 B
+            # over the launch's duration, 16-spp frame) carried from the profile named in carried_from; the peak is the lower end of the L2
+            # gather rate MI355X_MICROARCH.md measures (16.8-18.8 TB/s).  Executed tests: the counting build of this run.
+            "roofline": {"bound": "l2", "kernel": "k_pathtrace_bvh", "achieved": prof.get("c5_l2_GBps"), "peak": 16800.0, "unit": "GB/s",
+                         "frac": (prof["c5_l2_GBps"] / 16800.0) if prof.get("c5_l2_GBps") else None,
+                         "traffic": prof.get("c5_hbm_bytes_per_16spp_frame"), "carried_from": prof.get("carried_from"),
+                         "executed_flop_per_ray": ex.get("flop_per_ray"), "executed_bytes_per_ray": ex.get("bytes_per_ray"),
+                         "executed_TFLOPs": ex.get("executed_TFLOPs"), "requested_by_lanes_GBps": ex.get("fetched_GBps"),
+                         "frac_of_fp32_peak": (ex.get("executed_TFLOPs") or 0.0) / PEAK_FP32_TFLOPS,
+                         "note": "lines the vector L1s ask the L2 for (128 B each, for 32-byte nodes) per second against the L2 gather rate; "
+                                 "executed node-box tests (2 x 25 flop, 32 B per node) and object tests (27 flop, 32 B) per ray from the "
+                                 "counting build (SURVEY.md 8d C5)"},
             "cpu_baseline": d.get("cpu_baseline")}
     return res
 

@@ -47,6 +47,15 @@ if c3_out:
             if g.get("TCC_REQ_sum"):
                 c4 = {"c4_gather_l2_request_bytes_per_launch": 128.0 * g["TCC_REQ_sum"],
                       "c4_gather_hbm_bytes_per_launch": g.get("hbm_read_bytes_raw", 0.0) + g.get("hbm_write_bytes", 0.0)}
+        p5 = os.path.join(dst, f"{name}_c5_pmc.json")
+        if os.path.exists(p5):
+            g = next((v for k, v in json.load(open(p5)).items() if k.startswith("k_pathtrace_bvh<7, 22, false, false, true")), {})
+            if g.get("TCC_REQ_sum"):
+                # the PMC run of C5 renders 16 spp (profiles/run_all.sh): lines the vector L1s ask the L2 for, and the launch's duration
+                c4.update({"c5_l2_request_bytes_per_16spp_frame": 128.0 * g["TCC_REQ_sum"],
+                           "c5_16spp_frame_us_under_pmc": g.get("mean_duration_us_under_pmc"),
+                           "c5_l2_GBps": 128.0 * g["TCC_REQ_sum"] / (g["mean_duration_us_under_pmc"] * 1e-6) / 1e9,
+                           "c5_hbm_bytes_per_16spp_frame": g.get("hbm_read_bytes_raw", 0.0) + g.get("hbm_write_bytes", 0.0)})
         json.dump({"tag": name, "src_sha16": sha, **c4,
                    "k_pathtrace_hbm_bytes_per_launch": d["hbm_write_bytes"] + d.get("hbm_read_bytes_raw", 0.0),
                    "read_bytes": d.get("hbm_read_bytes_raw"), "write_bytes": d["hbm_write_bytes"],
