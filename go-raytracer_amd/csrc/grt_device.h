@@ -334,6 +334,19 @@ GRT_DEV f3 sample_hemi32(f3 n, float u1, float u2) {
   return mk3(fmaf(u.x, c, fmaf(v.x, s, n.x * w)), fmaf(u.y, c, fmaf(v.y, s, n.y * w)),
              fmaf(u.z, c, fmaf(v.z, s, n.z * w)));
 }
+// The same for a normal that is a signed unit axis (every face normal AABB.Surface returns, aabb.go:57-70): u and v of
+// the basis are signed axes too, so the result's components are +-c, +-s, +-w in some order — the general function's
+// own values bit for bit (its products with 0 and 1 are exact): n = +-e_x: u = (0, 0, -n.x), v = (0, 1, 0), result
+// (n.x w, s, -n.x c); n = +-e_y: u = (0, 0, n.y), v = (1, 0, 0), result (s, n.y w, n.y c); n = +-e_z: u = (0, -n.z, 0),
+// v = (1, 0, 0), result (s, -n.z c, n.z w).  16 VALU instead of 57; Cornell walls are boxes, so nearly every Lambert
+// bounce takes it.
+GRT_DEV f3 sample_hemi32_axis(f3 n, float u1, float u2) {
+  const float r2s = sqrt32(u2);
+  const float c = __builtin_amdgcn_cosf(u1) * r2s, s = __builtin_amdgcn_sinf(u1) * r2s;
+  const float w = sqrt32(1.0f - u2);
+  const bool ax = n.x != 0.0f, ay = n.y != 0.0f;
+  return mk3(ax ? n.x * w : s, ax ? s : (ay ? n.y * w : -n.z * c), ax ? -n.x * c : (ay ? n.y * c : n.z * w));
+}
 // vec3.go:129-131.  v and n are unit vectors, so v - 2(v.n)n is unit to rounding; the reference's Unit() is not
 // repeated (as in sample_hemi32).
 GRT_DEV f3 reflect32(f3 v, f3 n) { return fma3(n, -2.0f * dot3(v, n), v); }
@@ -663,9 +676,11 @@ GRT_DEV int intersect_primary_rel(const float* __restrict__ q, uint32_t box_mask
 }
 
 // Surface(p) from an already fetched object record (see surface32).
-GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3& n) {
+// axis (optional): set when n is a signed unit axis (a box face the epsilon cascade named), see sample_hemi32_axis
+GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3& n, bool* axis = nullptr) {
   int bits = __float_as_int(pb.w);
   p = fma3(r.D, t, r.O);
+  if (axis) *axis = false;
   if (bits & 1) {
     float nx = fminf((pa.x - r.O.x) * r.invD.x, (pb.x - r.O.x) * r.invD.x);
     float ny = fminf((pa.y - r.O.y) * r.invD.y, (pb.y - r.O.y) * r.invD.y);
@@ -681,6 +696,7 @@ GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3
     n.x = cx ? (x0 ? -1.0f : 1.0f) : 0.0f;
     n.y = cy ? (y0 ? -1.0f : 1.0f) : 0.0f;
     n.z = cz ? (z0 ? -1.0f : 1.0f) : 0.0f;
+    if (axis) *axis = cx | cy | cz;
   } else {
     f3 d = mk3(p.x - pa.x, p.y - pa.y, p.z - pa.z);
     float s = rsq32(dot3(d, d));
@@ -693,9 +709,10 @@ GRT_DEV int surface_rec(float4 pa, float4 pb, const Ray32& r, float t, f3& p, f3
 // distances are the very values the loop took its max3 of, so the entry axis is the one that produced t (first
 // axis on ties), and the near bound of that axis is the face the hit point is snapped to.  The epsilon cascade
 // of aabb.go:57-70 runs on MinBound / MaxBound (pa, pb) as in the reference.
-GRT_DEV int surface_rec_oct(float4 pa, float4 pb, const float* __restrict__ q, const Ray32& r, float t, f3& p, f3& n) {
+GRT_DEV int surface_rec_oct(float4 pa, float4 pb, const float* __restrict__ q, const Ray32& r, float t, f3& p, f3& n, bool* axis = nullptr) {
   const int bits = __float_as_int(pb.w);
   p = fma3(r.D, t, r.O);
+  if (axis) *axis = false;
   if (bits & 1) {
     const float4 qa = *(const float4*)q;
     const float nx = fmaf(qa.x, r.invD.x, -r.OinvD.x), ny = fmaf(qa.y, r.invD.y, -r.OinvD.y), nz = fmaf(qa.z, r.invD.z, -r.OinvD.z);
@@ -710,6 +727,7 @@ GRT_DEV int surface_rec_oct(float4 pa, float4 pb, const float* __restrict__ q, c
     n.x = cx ? (x0 ? -1.0f : 1.0f) : 0.0f;
     n.y = cy ? (y0 ? -1.0f : 1.0f) : 0.0f;
     n.z = cz ? (z0 ? -1.0f : 1.0f) : 0.0f;
+    if (axis) *axis = cx | cy | cz;
   } else {
     f3 d = mk3(p.x - pa.x, p.y - pa.y, p.z - pa.z);
     float s = rsq32(dot3(d, d));
@@ -874,7 +892,8 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   const int idc = hit ? id : 0;
   const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];
   f3 p, n;
-  const int m = octq ? surface_rec_oct(pa, pb, octq + 8 * idc, r, t, p, n) : surface_rec(pa, pb, r, t, p, n);  // scene.go:254-255
+  bool axis_n;  // the normal is a signed unit axis (a box face)
+  const int m = octq ? surface_rec_oct(pa, pb, octq + 8 * idc, r, t, p, n, &axis_n) : surface_rec(pa, pb, r, t, p, n, &axis_n);  // scene.go:254-255
   const float4 m0 = tm[GRT_MAT_STRIDE * m], m1 = tm[GRT_MAT_STRIDE * m + 1];
   const int flags = __float_as_int(m1.w);
   const f3 color = mk3(m0.x, m0.y, m0.z);
@@ -972,7 +991,9 @@ GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const fl
   } else {
     L.O = p;
     if (is_lamb) {                                  // scene.go:280-286
-      L.D = sample_hemi32(n, u1, u2);
+      // box faces (every wall of the Cornell room): the basis is made of signed axes, same values in 16 VALU instead of 57
+      if (__any(!axis_n)) L.D = sample_hemi32(n, u1, u2);
+      else L.D = sample_hemi32_axis(n, u1, u2);
       L.thr = L.thr * color;
     } else if (is_metal) {
       L.D = dir;
