@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_photon_trace(KScene S, float4 light_pos
   const grt_key key = grt_rng_path_key(grt_rng_pixel_key(S.seed32, (uint32_t)e),
                                         (uint32_t)(caustics ? 1 : 0) + 2u * (uint32_t)(e >> 32));
   f3 O = mk3(light_pos.x, light_pos.y, light_pos.z);  // l.Pos(), scene.go:149
-  f3 D = sample_hemi32(mk3(0.0f, -1.0f, 0.0f), grt_rng_draw(key, GRT_PDIM_EMIT_U), grt_rng_draw(key, GRT_PDIM_EMIT_V));
+  // nl = (0, -1, 0) (scene.go:150): a signed axis, the basis of SampleHemisphereNormal is made of axes (same values, fewer instructions)
+  f3 D = sample_hemi32_axis(mk3(0.0f, -1.0f, 0.0f), grt_rng_draw(key, GRT_PDIM_EMIT_U), grt_rng_draw(key, GRT_PDIM_EMIT_V));
   f3 power = mk3(power0.x, power0.y, power0.z);
   bool alive = valid, stored = false;
   f3 sp = mk3(0, 0, 0), spow = mk3(0, 0, 0);
