@@ -52,6 +52,10 @@ GRT_DEV void bvh_ray_setup(BvhRay& g, const RAY& r, const BvhGrid& G) {
 
 template <bool CAREFUL>
 GRT_DEV bool bvh_box(uint4 q, const BvhRay& r, f3 Og, float tbest, float& tn) {
+#ifdef GRT_NOCULL  // experiment (tools/exp_c5_pixels.py): no box is ever culled, the walk becomes the linear scan in tree order
+  tn = 0.0f;
+  return true;
+#endif
   const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
   const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
   float x0, x1, y0, y1, z0, z1;

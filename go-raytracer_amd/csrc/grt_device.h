@@ -91,6 +91,8 @@ struct KScene {
   // scenes above GRT_MAX_LINEAR_PRIMS objects (or grt_scene_desc.accel = GRT_ACCEL_BVH): grt_bvh.h
   const uint4* __restrict__ bvh_nodes;
   const float4* __restrict__ bvh_prims;
+  const uint4* __restrict__ bvh8_nodes;   // grt_bvh8.h: the 8-wide form of the same tree (NULL: not built)
+  const float4* __restrict__ bvh8_prims;  // the object records in ITS leaf order
   BvhGrid bvh_grid;
   int bvh_depth;
   int n_mats;
@@ -373,6 +375,7 @@ GRT_DEV bool refract32(f3 v, f3 n, float4 m2, float xi, f3& out) {
 }
 
 #include "grt_bvh.h"
+#include "grt_bvh8.h"
 
 // ---- one camera path as a per-lane state machine ------------------------------------------
 // Scene.trace (scene.go:237-349) is recursive with at most max_depth-1 levels and every level
@@ -888,6 +891,14 @@ template <int QUEUE, int DIRECT, bool VIEW>
 GRT_DEV void path_shade(const KScene& S, const float4* __restrict__ tp, const float4* __restrict__ tm, float fx, float fy,
                         uint32_t pix_key, int s_end, LaneState& L, bool& alive, const Ray32& r, int id, float t, WaveQueue* Q,
                         const PmOut* pm, int pm_base, int* bvh_stack, int bvh_stride, const float* octq) {
+#ifdef GRT_TRACE_PATH  // experiment: the hits of one path, printed by whichever kernel traces it
+  {
+    const grt_key want = grt_rng_path_key(grt_rng_pixel_key(S.seed32, GRT_TRACE_PIXEL), GRT_TRACE_SAMPLE);
+    if (L.pkey.a == want.a && L.pkey.b == want.b)
+      printf("Q%d depth %d id %d t %.9g O %.9g %.9g %.9g D %.9g %.9g %.9g\n", QUEUE, L.depth, id, (double)t, (double)r.O.x, (double)r.O.y,
+             (double)r.O.z, (double)r.D.x, (double)r.D.y, (double)r.D.z);
+  }
+#endif
   const bool hit = id >= 0;                         // scene.go:244
   const int idc = hit ? id : 0;
   const float4 pa = tp[2 * idc], pb = tp[2 * idc + 1];
