@@ -182,8 +182,6 @@ static void free_device_scene(DeviceScene& d) {
   (void)hipFree(d.prims64);
   (void)hipFree(d.bvh_nodes);
   (void)hipFree(d.bvh_prims);
-  (void)hipFree(d.bvh8_nodes);
-  (void)hipFree(d.bvh8_prims);
   (void)hipFree(d.tile_live);
   d = DeviceScene();
 }
@@ -300,114 +298,6 @@ static int bvh_build(BvhBuild& B, int a, int b, float* lo, float* hi, int depth,
   return me;
 }
 
-// The 8-wide form of the binary tree (grt_bvh8.h).  A wide node starts from a binary node's two children and keeps
-// replacing the inner child of largest surface by its two children until it has eight; leaves are single objects.
-// Nodes are numbered breadth first, so the inner children of a node are consecutive, and the objects are laid out in
-// the order the nodes name them, so a node's leaf children are consecutive too.  Returns false (nothing built) for
-// trees this form does not cover: leaves of several objects, more than 2^22 nodes, deeper than its stack.
-static bool wide_from_binary(const BvhBuild& B, int n, const std::vector<float4>& hp, float eye_r, std::vector<uint4>& wn,
-                             std::vector<float4>& wp, int* depth_out) {
-  if (B.leaf != 1 || n < 2 || n >= (1 << 24)) return false;
-  struct Ch {
-    int ref;
-    float lo[3], hi[3];
-  };
-  auto child = [&](int node, int c) {
-    Ch ch;
-    const float4 l = B.nodes[4 * (size_t)node + 2 * c], h = B.nodes[4 * (size_t)node + 2 * c + 1];
-    ch.ref = __builtin_bit_cast(int, l.w);
-    ch.lo[0] = l.x, ch.lo[1] = l.y, ch.lo[2] = l.z, ch.hi[0] = h.x, ch.hi[1] = h.y, ch.hi[2] = h.z;
-    return ch;
-  };
-  auto empty = [](const Ch& c) { return c.ref < 0 && ((~c.ref) & 7) == 0; };
-  auto area = [](const Ch& c) {
-    const double x = (double)c.hi[0] - c.lo[0], y = (double)c.hi[1] - c.lo[1], z = (double)c.hi[2] - c.lo[2];
-    return x * y + y * z + z * x;
-  };
-  struct Pending {
-    int bnode, depth;
-  };
-  std::vector<Pending> queue{{0, 1}};
-  wn.clear();
-  wp.assign(2 * (size_t)n, make_float4(0, 0, 0, 0));
-  int next_w = 1, next_o = 0, max_depth = 1;
-  for (size_t head = 0; head < queue.size(); ++head) {
-    const Pending p = queue[head];
-    max_depth = std::max(max_depth, p.depth);
-    std::vector<Ch> ch;
-    for (int c = 0; c < 2; ++c) {
-      const Ch x = child(p.bnode, c);
-      if (!empty(x)) ch.push_back(x);
-    }
-    while (ch.size() < 8) {
-      int pick = -1;
-      double best = -1.0;
-      for (size_t i = 0; i < ch.size(); ++i)
-        if (ch[i].ref >= 0 && area(ch[i]) > best) best = area(ch[i]), pick = (int)i;
-      if (pick < 0) break;
-      const int b = ch[pick].ref;
-      ch.erase(ch.begin() + pick);
-      for (int c = 0; c < 2; ++c) {
-        const Ch x = child(b, c);
-        if (!empty(x)) ch.push_back(x);
-      }
-    }
-    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-    for (const Ch& c : ch)
-      for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], c.lo[k]), hi[k] = std::max(hi[k], c.hi[k]);
-    int axis = 0;
-    if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
-    if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
-    std::stable_sort(ch.begin(), ch.end(), [axis](const Ch& a, const Ch& b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis]; });
-    uint32_t inner_mask = 0;
-    const int child_base = next_w, leaf_base = next_o;
-    for (size_t i = 0; i < ch.size(); ++i) {
-      if (ch[i].ref >= 0) {
-        inner_mask |= 1u << i;
-        queue.push_back({ch[i].ref, p.depth + 1});
-        next_w++;
-      } else {
-        if (((~ch[i].ref) & 7) != 1) return false;  // leaves of one object only
-        const int o = B.items[(size_t)((~ch[i].ref) >> 3)].idx;
-        float4 pb = hp[2 * (size_t)o + 1];
-        pb.w = __builtin_bit_cast(float, (uint32_t)o << 3 | ((uint32_t)__builtin_bit_cast(int, pb.w) & 7u));
-        wp[2 * (size_t)next_o] = hp[2 * (size_t)o], wp[2 * (size_t)next_o + 1] = pb;
-        next_o++;
-      }
-    }
-    if (next_w >= (1 << 22)) return false;
-    // the node's 8-bit grid: 253 cells span its box, child boxes round outward and take one more cell
-    float sc[3];
-    uint32_t ql[3][8] = {}, qh[3][8] = {};
-    for (int k = 0; k < 3; ++k) {
-      const double ext = (double)hi[k] - (double)lo[k];
-      const double reach = std::max({std::fabs((double)lo[k]), std::fabs((double)hi[k]), (double)eye_r});
-      float sf = (float)std::max(ext / 253.0, 2e-6 * reach + 1e-30);
-      while ((double)sf * 253.0 < ext) sf = std::nextafter(sf, 3e38f);
-      sc[k] = sf;
-      for (size_t i = 0; i < ch.size(); ++i) {
-        const double a = std::floor(((double)ch[i].lo[k] - (double)lo[k]) / (double)sf) - 1.0;
-        const double b = std::ceil(((double)ch[i].hi[k] - (double)lo[k]) / (double)sf) + 1.0;
-        ql[k][i] = (uint32_t)std::min(255.0, std::max(0.0, a)), qh[k][i] = (uint32_t)std::min(255.0, std::max(0.0, b));
-      }
-    }
-    auto pack4 = [](const uint32_t* q, int first) { return q[first] | q[first + 1] << 8 | q[first + 2] << 16 | q[first + 3] << 24; };
-    const uint32_t w0 = (uint32_t)child_base | (uint32_t)axis << 22 | (uint32_t)ch.size() << 24;
-    const uint32_t w1 = (uint32_t)leaf_base | inner_mask << 24;
-    auto fb = [](float f) { return __builtin_bit_cast(uint32_t, f); };
-    const size_t at = wn.size();
-    wn.resize(at + GRT_BVH8_NODE_QUADS, make_uint4(0, 0, 0, 0));
-    wn[at + 0] = make_uint4(fb(lo[0]), fb(lo[1]), fb(lo[2]), fb(sc[0]));
-    wn[at + 1] = make_uint4(fb(sc[1]), fb(sc[2]), w0, w1);
-    wn[at + 2] = make_uint4(pack4(ql[0], 0), pack4(ql[0], 4), pack4(ql[1], 0), pack4(ql[1], 4));
-    wn[at + 3] = make_uint4(pack4(ql[2], 0), pack4(ql[2], 4), pack4(qh[0], 0), pack4(qh[0], 4));
-    wn[at + 4] = make_uint4(pack4(qh[1], 0), pack4(qh[1], 4), pack4(qh[2], 0), pack4(qh[2], 4));
-  }
-  if (next_o != n || (int)(wn.size() / GRT_BVH8_NODE_QUADS) != next_w || max_depth > GRT_BVH8_STACK) return false;
-  *depth_out = max_depth;
-  return true;
-}
-
 static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceScene& d) {
   const int n = (int)s->prims.size();
   StageClock clk;
@@ -477,12 +367,6 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     d.bvh_grid[c] = gmin[c], d.bvh_grid[3 + c] = gs[c], d.bvh_grid[6 + c] = 1.0f / gs[c];
   }
   clk.lap("hierarchy: leaf records, grid");
-  // the 8-wide form for the render kernel (scenes whose every query goes through k_pathtrace_bvh8: no plain-diffuse object)
-  std::vector<uint4> wn;
-  std::vector<float4> wp;
-  int wdepth = 0;
-  const bool wide = !s->has_diffuse && !getenv("GRT_NO_BVH8") && wide_from_binary(B, n, hp, eye_r, wn, wp, &wdepth);
-  clk.lap("hierarchy: 8-wide form");
   d.bvh_depth = B.max_depth.load();
   // Memory order of the nodes: the inner children of a node are neighbours (one 64-byte pair, even
   // slot first), followed by the pair of the first child's children, then the rest of the first
@@ -541,13 +425,6 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   GRT_HIP(hipMalloc(&d.bvh_prims, bp.size() * sizeof(float4)));
   GRT_HIP(hipMemcpy(d.bvh_nodes, qn.data(), qn.size() * sizeof(uint4), hipMemcpyHostToDevice));
   GRT_HIP(hipMemcpy(d.bvh_prims, bp.data(), bp.size() * sizeof(float4), hipMemcpyHostToDevice));
-  if (wide) {
-    GRT_HIP(hipMalloc(&d.bvh8_nodes, wn.size() * sizeof(uint4)));
-    GRT_HIP(hipMalloc(&d.bvh8_prims, wp.size() * sizeof(float4)));
-    GRT_HIP(hipMemcpy(d.bvh8_nodes, wn.data(), wn.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    GRT_HIP(hipMemcpy(d.bvh8_prims, wp.data(), wp.size() * sizeof(float4), hipMemcpyHostToDevice));
-    d.bvh8_depth = wdepth;
-  }
   clk.lap("hierarchy: upload");
   return GRT_OK;
 }
@@ -731,7 +608,6 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
   k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_depth = d.bvh_depth;
-  k.bvh8_nodes = d.bvh8_nodes, k.bvh8_prims = d.bvh8_prims;
   k.n_mats = (int)s->mats.size();
   k.bvh_grid.gmin = {d.bvh_grid[0], d.bvh_grid[1], d.bvh_grid[2]};
   k.bvh_grid.gs = {d.bvh_grid[3], d.bvh_grid[4], d.bvh_grid[5]};
@@ -903,13 +779,6 @@ int grt_render_dev_internal(grt_scene* s, const grt_opts* o, int shard, int n_sh
 #else
     hipLaunchKernelGGL((k_pathtrace_bvh<6, GRT_BVH_STACK, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
 #endif
-  } else if (s->use_bvh && ks.bvh8_nodes && !s->has_diffuse && (variant == 11 || variant == 12)) {  // the 8-wide walk (grt_bvh8.h)
-    if (variant == 12) {
-      if (!rcnt) return grt_fail(GRT_EINVAL, "render variant 12 counts into d_ray_count[0..2]: a NULL counter was passed");
-      hipLaunchKernelGGL((k_pathtrace_bvh8<5, true>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
-    } else {
-      hipLaunchKernelGGL((k_pathtrace_bvh8<5>), dim3(grid), dim3(256), 0, st, ks, j, target, rcnt);
-    }
   } else if (s->use_bvh) {
     const char* e = getenv("GRT_BVH_OCC");
     const int occ = e ? atoi(e) : 7;

@@ -91,8 +91,6 @@ struct KScene {
   // scenes above GRT_MAX_LINEAR_PRIMS objects (or grt_scene_desc.accel = GRT_ACCEL_BVH): grt_bvh.h
   const uint4* __restrict__ bvh_nodes;
   const float4* __restrict__ bvh_prims;
-  const uint4* __restrict__ bvh8_nodes;   // grt_bvh8.h: the 8-wide form of the same tree (NULL: not built)
-  const float4* __restrict__ bvh8_prims;  // the object records in ITS leaf order
   BvhGrid bvh_grid;
   int bvh_depth;
   int n_mats;
@@ -375,7 +373,6 @@ GRT_DEV bool refract32(f3 v, f3 n, float4 m2, float xi, f3& out) {
 }
 
 #include "grt_bvh.h"
-#include "grt_bvh8.h"
 
 // ---- one camera path as a per-lane state machine ------------------------------------------
 // Scene.trace (scene.go:237-349) is recursive with at most max_depth-1 levels and every level

@@ -127,8 +127,9 @@ GRT_DEV void load_tables(const KScene& S, float4* lds, SceneTables<NP>& T, float
 #define GRT_PT_WAVES 8
 #endif
 template <int NP, bool RELOAD = false, bool PREFETCH = false, bool QUEUE = false, bool VIEW = false>
-// The production instance for scenes of <= 8 objects is compiled for 7 waves per SIMD (72 VGPRs, 24 B of
-// scratch): 37.5 ms against 38.1 ms at 6 waves (76 VGPRs) for the C3 frame; 8 waves (64 VGPRs) the same.
+// The production instance for scenes of <= 8 objects is compiled for 8 waves per SIMD (64 VGPRs).  Round 3, same box, built
+// without SLP vectorisation (csrc/Makefile): C3 at 1920x1080 7.15 ms at 7 waves, 6.93 ms at 8, 8.03 ms at 6 (with SLP: 7.70 /
+// 7.62 / 8.03); rounds 1-2 ran it at 7 (37.5 ms against 38.1 ms at 6 for the full frame, 8 the same).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NP == GRT_FAST_PRIMS && RELOAD && !PREFETCH && !QUEUE) ? GRT_PT_WAVES : 4)))
 void k_pathtrace(KScene S, RenderJob J, float* __restrict__ out,
                                                    unsigned long long* __restrict__ ray_count) {
@@ -391,124 +392,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         for (int k = 0; k < 3; ++k) atomicAdd(ray_count + 3 + k, (unsigned long long)c_steps[k]), atomicAdd(ray_count + 6 + k, (unsigned long long)c_lanes[k]);
         atomicAdd(ray_count + 9, (unsigned long long)c_rounds), atomicAdd(ray_count + 10, (unsigned long long)c_alive);
       }
-    }
-  }
-}
-
-// k_pathtrace_bvh over the 8-wide form of the hierarchy (grt_bvh8.h): the same work items, wave queue, fixed-point pixel
-// sums and three-way scheduling (inner child / leaf child / shading); only the walk differs, so the frame is the binary
-// kernel's bit for bit (the winner of a ray does not depend on the order in which objects are met).  Scenes without
-// plain-diffuse objects (their shadow and photon queries walk the binary tree).
-// COUNT: ray_count[1] += wide nodes fetched, [2] += objects tested.
-template <int WAVES, bool COUNT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_pathtrace_bvh8(
-    KScene S, RenderJob J, float* __restrict__ out, unsigned long long* __restrict__ ray_count) {
-  __shared__ int bvh_stack[2 * GRT_BVH8_STACK * 256];  // [wave][2 x depth][lane]
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= J.n_tiles * J.n_chunks) return;  // wave-uniform
-  const int tile = item % J.n_tiles, chunk = item / J.n_tiles;
-  const int tx = tile % J.tiles_x, lband = tile / J.tiles_x;
-  const int x = tx * 8 + (lane & 7);
-  const int y = (J.shard + lband * J.n_shards) * 8 + (lane >> 3);
-  const int lrow = lband * 8 + (lane >> 3);
-  const bool valid = (x < S.W) & (y < S.H);
-  const int s0 = J.s_first + J.chunk_start[chunk];
-  const int s_end = J.s_first + J.chunk_start[chunk + 1];
-  uint32_t pix_key = grt_rng_pixel_key(S.seed32, (uint32_t)y * (uint32_t)S.W + (uint32_t)x);
-  float fx = (float)x, fy = (float)y;
-  int n_rays = 0;
-  const bool culled = S.tile_live && !S.tile_live[(J.shard + lband * J.n_shards) * J.tiles_x + tx];  // wave-uniform
-  bool alive = (s0 < s_end) & !culled;
-  LaneState L;
-  lane_begin(S, fx, fy, pix_key, s0, L);
-  L.pix = lane;
-  WaveQueue Q;
-  Q.acc = nullptr, Q.pixkey = nullptr;
-  Q.s0 = s0, Q.x0 = tx * 8, Q.y0 = (J.shard + lband * J.n_shards) * 8;
-  Q.next = 64, Q.qend = 64 * (s_end - s0);
-  long long sum_x = 0, sum_y = 0, sum_z = 0;  // this lane's PIXEL, fixed point
-  UnitRay r;
-  Bvh8Ray g;
-  Bvh8Walk wk;
-  r.O = L.O, r.D = L.D;
-  bvh8_ray_setup(g, r);
-  bvh8_walk_begin(wk);
-  if (!alive || !valid) bvh8_walk_end(wk);  // (a pair outside the frame is born finished: it reaches shading as a miss)
-  int* stack = bvh_stack + 2 * GRT_BVH8_STACK * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int n_inner = 0, n_objs = 0, c_rounds = 0, c_walk = 0, c_walk_max = 0, c_sp_max = 0;
-  for (;;) {
-    if (COUNT) c_rounds++;
-    const bool at_inner = bvh8_at_inner(wk, r.D), at_leaf = bvh8_at_leaf(wk, r.D);
-    const bool to_shade = alive & !at_inner & !at_leaf;
-    const unsigned long long mI = __ballot(at_inner), mL = __ballot(at_leaf), mS = __ballot(to_shade);
-    const int nI = __builtin_popcountll(mI), nL = __builtin_popcountll(mL), nS = __builtin_popcountll(mS);
-    if ((nI | nL | nS) == 0) break;
-    if (nS >= J.shade_min || (nI | nL) == 0) {
-      int owner = 0;
-      f3 give = mk3(0.0f, 0.0f, 0.0f);
-      if (to_shade) {
-        float t;
-        const int id = bvh8_walk_result(wk, t);
-        Ray32 fr;
-        ray_setup_unit(fr, r.O, r.D);
-        L.O = r.O, L.D = r.D;
-        owner = L.pix;
-        const int px = Q.x0 + (L.pix & 7), py = Q.y0 + (L.pix >> 3);
-        n_rays += (px < S.W) & (py < S.H);  // scene.go:242; a pair outside the frame made no call
-        path_shade<2, 1>(S, S.prims, S.mats, fx, fy, pix_key, s_end, L, alive, fr, id, t, &Q, &J.pm, 0, stack, 0);
-        give = L.acc;
-        if (alive) {
-          r.O = L.O, r.D = L.D;
-          bvh8_ray_setup(g, r);
-          bvh8_walk_begin(wk);
-          if (COUNT) c_walk = 0;
-          if (!((Q.x0 + (L.pix & 7) < S.W) & (Q.y0 + (L.pix >> 3) < S.H))) bvh8_walk_end(wk);
-        }
-      }
-      Q.next += __builtin_popcountll(__ballot(to_shade & (L.depth == 1)));  // the pairs path_shade has just handed out
-      unsigned long long m = __ballot(to_shade & ((give.x != 0.0f) | (give.y != 0.0f) | (give.z != 0.0f)));
-      while (m) {  // usually empty: most levels carry no radiance
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const int p = __builtin_amdgcn_readlane(owner, l);
-        const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.x), l));
-        const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.y), l));
-        const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(give.z), l));
-        int me;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(me));
-        if (me == p) {
-          sum_x += __double2ll_rn((double)cx * J.acc_scale);
-          sum_y += __double2ll_rn((double)cy * J.acc_scale);
-          sum_z += __double2ll_rn((double)cz * J.acc_scale);
-        }
-      }
-    } else if (nI * J.inner_weight >= nL * 4) {
-      if (COUNT) n_inner += at_inner, c_walk += at_inner, c_walk_max = max(c_walk_max, c_walk), c_sp_max = max(c_sp_max, wk.sp);
-      if (at_inner) bvh8_inner_step(S.bvh8_nodes, r, g, wk, stack);
-      if (COUNT && c_walk == 50000) {
-        ray_count[5] = __float_as_uint(r.O.x), ray_count[6] = __float_as_uint(r.O.y), ray_count[7] = __float_as_uint(r.O.z);
-        ray_count[10] = __float_as_uint(r.D.x), ray_count[11] = __float_as_uint(r.D.y), ray_count[12] = __float_as_uint(r.D.z);
-        ray_count[13] = __float_as_uint(wk.H.tbest), ray_count[14] = (unsigned)L.depth;
-      }
-    } else {
-      if (COUNT) n_objs += at_leaf;
-      if (at_leaf) bvh8_leaf_step(S.bvh8_prims, r, S.bias, wk, stack);
-    }
-  }
-  if (valid) {
-    float* o = out + (((size_t)chunk * (size_t)J.rows_local + (size_t)lrow) * (size_t)S.W + (size_t)x) * 3;
-    o[0] = (float)((double)sum_x * J.acc_inv);
-    o[1] = (float)((double)sum_y * J.acc_inv);
-    o[2] = (float)((double)sum_z * J.acc_inv);
-  }
-  if (ray_count) {
-    unsigned long long tot = wave_sum_u32((unsigned)n_rays);
-    if (lane == 0) atomicAdd(ray_count, tot);
-    if (COUNT) {
-      const unsigned long long ti = wave_sum_u32((unsigned)n_inner), to = wave_sum_u32((unsigned)n_objs);
-      if (lane == 0) atomicAdd(ray_count + 1, ti), atomicAdd(ray_count + 2, to), atomicAdd(ray_count + 9, (unsigned long long)c_rounds);
-      atomicMax(ray_count + 3, (unsigned long long)c_walk_max), atomicMax(ray_count + 4, (unsigned long long)c_sp_max);
     }
   }
 }
