@@ -3,7 +3,7 @@
 # Kernel-trace summaries for the four measured configs, then PMC passes for every config.
 # Results under gpurun_out/<tag>/; profiles/collect.py copies the summaries into profiles/.
 set -u
-TAG=${1:-r03b}
+TAG=${1:-r03c}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
