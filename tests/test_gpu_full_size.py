@@ -97,6 +97,41 @@ def test_c5_full_scene_is_independent_of_scheduling_and_sample_split(pkg, shard,
     assert torch.allclose(total, whole, rtol=1e-5, atol=1e-6)
 
 
+def test_c5_every_kernel_computes_the_same_path(pkg, shard):
+    """One value per expression: the per-lane walk of grt_trace_samples, the wave-queue kernel and the
+    lane = pixel kernel are three instantiations of the same inline functions and must return the same radiance for
+    every (pixel, sample).  The C5 scene amplifies an ulp within two bounces; the pixels below are the 16 of 2 073 600
+    on which the kernels disagreed while the backend was free to fuse a*b - c*d differently per instantiation
+    (hipcc's default -ffp-contract=fast), plus a band of ordinary ones."""
+    import torch
+
+    W, H, S = 1920, 1080, 16
+    pixels = [(1123, 152), (706, 164), (1309, 165), (763, 171), (1017, 178), (1158, 186), (1124, 229), (1086, 245), (814, 270),
+              (747, 283), (1162, 290), (886, 297), (815, 394), (637, 416), (1106, 418), (1246, 508)]
+    pixels += [(x, 300) for x in range(0, W, 16)]
+    scene = pkg.scenes.spheres(1000000, W, H)
+    per_sample, n_rays = scene.TraceSamples(np.array(pixels, np.int32), S, seed=1)
+    want = per_sample.astype(np.float64).sum(axis=1)
+    xs, ys = [p[0] for p in pixels], [p[1] for p in pixels]
+    for flags in (0, 8):
+        ren = shard.SampleShardRenderer(scene, S, 0, 1, seed=1)
+        ren.opts.flags = flags
+        ren.ray_count.zero_()
+        ren.render()
+        torch.cuda.synchronize()
+        got = ren.rgb_sum.cpu().numpy()[ys, xs].astype(np.float64)
+        # same paths: the sums differ only by their own rounding (64-bit fixed point / FP32 in sample order);
+        # a path that went another way moves a pixel by a light's worth (>= 0.4)
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, want.max()), flags
+    # and sample by sample: one frame per sample from the queue kernel
+    for s in (1, 7, 12):
+        one = shard.SampleShardRenderer(scene, S, s, S, seed=1)
+        one.render()
+        torch.cuda.synchronize()
+        got = one.rgb_sum.cpu().numpy()[ys, xs]
+        assert np.allclose(got, per_sample[:, s], rtol=2e-6, atol=1e-7), s
+
+
 def test_c5_full_scene_at_its_baseline_sample_count(pkg, shard, monkeypatch):
     """C5 at BASELINE's 256 spp (the sample count the fixed-point pixel sums are sized for): the production frame
     (wave queue, 64-bit fixed-point sums) is bit-identical under another scheduling setting, equals the lane = pixel
