@@ -394,6 +394,22 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
     }
   }
   clk.lap("hierarchy: node order");
+#ifdef GRT_COUNT_DEPTH
+  {
+    auto child = [&](int node, int c) { return __builtin_bit_cast(int, B.nodes[4 * (size_t)node + 2 * c].w); };
+    std::vector<uint8_t> sd(node_at.size(), 0);
+    std::vector<std::pair<int, int>> todo{{0, 0}};
+    while (!todo.empty()) {
+      const auto [nd, dp] = todo.back();
+      todo.pop_back();
+      sd[slot_of[nd]] = (uint8_t)dp;
+      for (int c : {child(nd, 0), child(nd, 1)})
+        if (c >= 0) todo.push_back({c, dp + 1});
+    }
+    GRT_HIP(hipMalloc(&d.bvh_slot_depth, sd.size()));
+    GRT_HIP(hipMemcpy(d.bvh_slot_depth, sd.data(), sd.size(), hipMemcpyHostToDevice));
+  }
+#endif
   const size_t n_nodes = node_at.size();
   std::vector<uint4> qn(2 * n_nodes, make_uint4(0, 0, 0, (uint32_t)~0));
   std::atomic<bool> grid_ok{true};
@@ -608,6 +624,9 @@ int grt_scene_kernel_view(grt_scene* s, uint64_t seed, KScene* ks) {
     if (s->prims[i].kind == GRT_KIND_AABB) k.box_mask |= 1u << i;
   k.prims = d.prims, k.mats = d.mats, k.lights = d.lights;
   k.bvh_nodes = d.bvh_nodes, k.bvh_prims = d.bvh_prims, k.bvh_depth = d.bvh_depth;
+#ifdef GRT_COUNT_DEPTH
+  k.bvh_slot_depth = d.bvh_slot_depth;
+#endif
   k.n_mats = (int)s->mats.size();
   k.bvh_grid.gmin = {d.bvh_grid[0], d.bvh_grid[1], d.bvh_grid[2]};
   k.bvh_grid.gs = {d.bvh_grid[3], d.bvh_grid[4], d.bvh_grid[5]};

@@ -93,6 +93,9 @@ struct KScene {
   const float4* __restrict__ bvh_prims;
   BvhGrid bvh_grid;
   int bvh_depth;
+#ifdef GRT_COUNT_DEPTH  // experiment (tools/exp_c5_treelets.py): depth of the node in every slot of bvh_nodes
+  const uint8_t* __restrict__ bvh_slot_depth;
+#endif
   int n_mats;
   // tile_live[ty * tiles_x + tx] == 0: no camera ray through 8x8 tile (tx, ty) can reach the scene's
   // bounding box (frustum-plane test in float64 on the host, grt_api.hip); its pixels are black

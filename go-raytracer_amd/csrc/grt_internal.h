@@ -47,6 +47,9 @@ struct DeviceScene {
   double* prims64 = nullptr;
   uint4* bvh_nodes = nullptr;  // grt_bvh.h; NULL for linear-scan scenes
   float4* bvh_prims = nullptr;
+#ifdef GRT_COUNT_DEPTH
+  uint8_t* bvh_slot_depth = nullptr;
+#endif
   int bvh_depth = 0;            // deepest leaf: the traversal stack holds at most this many entries + 1
   float bvh_grid[9] = {0, 0, 0, 1, 1, 1, 1, 1, 1};  // origin, cell size, 1 / cell size
   uint8_t* tile_live = nullptr;  // per 8x8 tile of the frame: can a camera ray reach the scene bounds?

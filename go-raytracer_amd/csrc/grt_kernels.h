@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
   unsigned long long zmask = __ballot(alive & ray_has_zero(r));  // lanes whose ray needs the careful box form
   int n_inner = 0, n_objs = 0;
   unsigned c_steps[3] = {0, 0, 0}, c_lanes[3] = {0, 0, 0}, c_alive = 0, c_rounds = 0;  // COUNT: wave-uniform
+#ifdef GRT_COUNT_DEPTH
+  unsigned c_depth[4] = {0, 0, 0, 0};  // per lane
+#endif
   for (;;) {
     // Three kinds of step — an inner node, a leaf, a trace() level's shading — and every lane is
     // ready for exactly one of them (or has no samples left).  The wave runs the step most lanes
@@ -340,6 +343,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
       zmask = (zmask & ~mS) | __ballot(to_shade & alive & ray_has_zero(r));
     } else if (nI * J.inner_weight >= nL * 4) {
       if (COUNT) n_inner += at_inner, c_steps[0]++, c_lanes[0] += nI;
+#ifdef GRT_COUNT_DEPTH  // ray_count[11 + r] += node visits at depth = r (mod 3); [14] += visits at depth >= 17
+      if (COUNT && at_inner) {
+        const int dp = S.bvh_slot_depth[wk.ref];
+        c_depth[dp % 3]++, c_depth[3] += dp >= 17;
+      }
+#endif
       if (at_inner) {
         if (zmask & mI) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
         else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
@@ -351,6 +360,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         const unsigned long long mA = __ballot(again);
         if (__builtin_popcountll(mA) < J.inner_again) break;
         if (COUNT) n_inner += again, c_steps[0]++, c_lanes[0] += __builtin_popcountll(mA), c_rounds++, c_alive += nI + nL + nS;
+#ifdef GRT_COUNT_DEPTH
+        if (COUNT && again) {
+          const int dp = S.bvh_slot_depth[wk.ref];
+          c_depth[dp % 3]++, c_depth[3] += dp >= 17;
+        }
+#endif
         if (again) {
           if (zmask & mA) bvh_inner_step<true>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
           else bvh_inner_step<false>(S.bvh_nodes, S.bvh_grid, r, g, wk, stack, 0);
@@ -392,6 +407,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         for (int k = 0; k < 3; ++k) atomicAdd(ray_count + 3 + k, (unsigned long long)c_steps[k]), atomicAdd(ray_count + 6 + k, (unsigned long long)c_lanes[k]);
         atomicAdd(ray_count + 9, (unsigned long long)c_rounds), atomicAdd(ray_count + 10, (unsigned long long)c_alive);
       }
+#ifdef GRT_COUNT_DEPTH
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long t = wave_sum_u32(c_depth[k]);
+        if (lane == 0) atomicAdd(ray_count + 11 + k, t);
+      }
+#endif
     }
   }
 }
