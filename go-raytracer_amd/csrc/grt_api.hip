@@ -324,8 +324,8 @@ static int stage_bvh(const grt_scene* s, const std::vector<float4>& hp, DeviceSc
   clk.lap("hierarchy: object boxes");
   B.nodes.resize(4 * (size_t)std::max(1, n));
   float lo[3], hi[3];
-  // Leaves of 2 objects walk fastest (measured at C5); deeper scenes take larger leaves so that the
-  // balanced tree fits the per-lane traversal stack.
+  // Leaves of one object (GRT_BVH_LEAF) by default (GRT_BVH_LEAF_OBJS: A/B knob); scenes too deep for the per-lane traversal
+  // stack take larger leaves.
   if (const char* e = getenv("GRT_BVH_LEAF_OBJS")) B.leaf = std::max(1, std::min(7, atoi(e)));  // A/B knob
   while (B.leaf < 7 && (((long long)B.leaf << (GRT_BVH_STACK - 2)) < (long long)n)) B.leaf = B.leaf < 2 ? 2 : (B.leaf < 4 ? 4 : 7);
   if (n <= B.leaf) {  // a single leaf still needs a root node: the second child is empty
