@@ -1047,45 +1047,15 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     };
 
     if (T.n > 0) {
-      if (bound == INFINITY) {
-        // No bound yet: nearest child first down to the nearest leaves until k photons are seen;
-        // their largest distance bounds the k-th.  The pool is then emptied and the walk below
-        // starts over with that bound.
-        int off = 0, nl = 1 << T.b0, prefix = 0;
-        for (int lvl = 0; lvl <= last; ++lvl) {
-          float d2box;
-          unsigned long long rem = test_group(lvl, off, prefix, bound, d2box);
-          const int nb = lvl == 0 ? T.b0 : KD_FAN_BITS;
-          if (rem == 0ull) break;  // nothing within the radius
-          while (rem) {
-            const bool in = (rem >> lane) & 1ull;
-            const uint32_t dmin = wave_total_min_u(in ? __float_as_uint(d2box) : 0xffffffffu);
-            const int l = __builtin_ctzll(__builtin_amdgcn_ballot_w64(in & (__float_as_uint(d2box) == dmin)));
-            rem &= ~(1ull << l);
-            if (lvl < last) {
-              prefix = (prefix << nb) | l;
-              break;
-            }
-            append_leaf((prefix << nb) | l, bound);
-            if (count >= k) break;
-          }
-          off += nl;
-          nl <<= KD_FAN_BITS;
-        }
-        if (count >= k) {
-          load_pool();
-          uint32_t m = 0;
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r) m = max(m, vb[r] == 0xffffffffu ? 0u : vb[r]);
-          bound = __uint_as_float(wave_total_max_u(m));
-          tight = true;
-        }
-        count = 0;
-      }
-
+      // A query with no bound yet (the first of a wave's range, or after a query that saw fewer than k photons) starts the walk
+      // below with bound = inf: nearest child first down to the nearest buckets, whose photons all enter the pool; as soon as k
+      // are in, their k-th distance becomes the bound, the buckets still pending are tested against it and every level's pending
+      // mask is tested again when the walk returns to it (`stale`).  (Until round 3 a separate descent found that first bound and
+      // the walk then started over: the nearest buckets were read twice.)
       // depth-first walk over the boxes within the bound
       int stk_lo = 0, stk_hi = 0;  // pending-children masks, level l in lane l
       int lvl = 0, off = 0, nl = 1 << T.b0, prefix = 0;
+      uint32_t stale = 0u;         // bit l: the bound has shrunk since level l's pending mask was made
       float d2box;
       unsigned long long mask = test_group(0, 0, 0, bound, d2box);
       for (;;) {
@@ -1095,8 +1065,15 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
             const int l = pick_child(mask, d2box);
             mask &= ~(1ull << l);
             append_leaf(pb | l, bound);
-            if (count > CAP - 64) reselect(true);
-            else if (!tight && count >= k) reselect(false);
+            const bool full = count > CAP - 64;
+            if (full || (!tight && count >= k)) {
+              const float was = bound;
+              reselect(full);
+              if (bound < was) {  // the buckets still pending were chosen under the old bound (d2box is this group's)
+                mask &= __builtin_amdgcn_ballot_w64(d2box <= bound);
+                stale = (1u << lvl) - 1u;
+              }
+            }
           }
         }
         if (mask == 0ull) {  // back to the parent's pending children
@@ -1107,6 +1084,10 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
           prefix >>= (lvl == 0 ? T.b0 : KD_FAN_BITS);
           mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(stk_hi, lvl) << 32) |
                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(stk_lo, lvl);
+          if (mask && ((stale >> lvl) & 1u)) {  // test this level's group again under the bound of now (one step; the distances are back too)
+            stale &= ~(1u << lvl);
+            mask &= test_group(lvl, off, prefix, bound, d2box);
+          }
           continue;
         }
         const int l = pick_child(mask, d2box);  // (a mask popped from the stack has lost its distances: index order)
@@ -1191,7 +1172,7 @@ GRT_API uint64_t grt_photon_gather_workspace_bytes(int32_t n) { return n > 0 ? (
 //   GRT_GATHER_STATS  per-launch totals on stderr (allocates and synchronises: tuning runs only)
 struct GatherTune {
   int qpw = 0, waves = 16;
-  float loose = 1.6f;
+  float loose = 6.0f;
   bool stats = false;
   GatherTune() {
     if (const char* e = getenv("GRT_GATHER_QPW")) qpw = atoi(e);
