@@ -287,8 +287,7 @@ def test_photon_map_view_matches_oracle(pkg, ob, accel):
 def test_gather_on_image_like_queries_with_empty_slots_and_far_queries(pkg, ob):
     """The shapes the photon-mapped render feeds the gather: runs of neighbouring queries on a dense sheet (the carried
     bound), NaN slots (no request), queries far outside the map, ties on a grid, with and without a radius — against
-    the oracle, query by query.  The chunk queue hands the runs to whichever wave is free: a query's estimate depends
-    on its own run only."""
+    the oracle, query by query."""
     rs = np.random.RandomState(5)
     n = 60000
     pos = rs.uniform(0, 555, (n, 3)).astype(np.float32)
@@ -314,3 +313,33 @@ def test_gather_on_image_like_queries_with_empty_slots_and_far_queries(pkg, ob):
         close = np.isclose(a[~holes], b, rtol=2e-4, atol=1e-9).all(1)
         assert close.mean() > 0.999, (radius, k, close.mean())
         assert (a == g.IrradianceEst(qn, nr, radius, k)).all()                             # the same answer whoever serves the run
+
+
+def test_gather_on_a_three_level_tree_matches_oracle(pkg, ob):
+    """600 000 photons = a box tree of three levels (4 x 64 x 64 buckets), the shape of C4's maps: the walk returns to levels
+    whose pending children were chosen under a bound that has shrunk since (k_gather_knn re-tests them), starts some queries
+    with no bound at all (the first of a wave's range, the one after a query beyond every photon's reach) and carries
+    bounds along runs of neighbours.  Query by query against the oracle, with and without a radius."""
+    rs = np.random.RandomState(23)
+    n = 600000
+    pos = rs.uniform(0, 555, (n, 3)).astype(np.float32)
+    pos[: n // 3, 1] = 0.1                                     # a floor sheet
+    pos[n // 3: n // 2, 0] = 555.0                             # and a wall
+    pos[n // 2: n // 2 + 20000] = (rs.normal(size=(20000, 3)) * 3 + np.array([168, 30, 187])).astype(np.float32)  # a dense blob
+    pw = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+    tp = rs.randint(0, 256, (n, 2)).astype(np.uint8)
+    g = pkg.tracer.PhotonMap.load(pos, pw, tp)
+    o = ob.OraclePhotonMap.load(pos.astype(np.float64), pw.astype(np.float64), tp)
+    xs, zs = np.meshgrid(np.linspace(140, 200, 40, dtype=np.float32), np.linspace(160, 220, 40, dtype=np.float32))
+    run = np.stack([xs.ravel(), np.full(xs.size, 0.1, np.float32), zs.ravel()], 1)         # neighbours across the blob's footprint
+    q = np.concatenate([run, rs.uniform(0, 555, (1200, 3)).astype(np.float32), rs.uniform(-2000, 3000, (200, 3)).astype(np.float32)])
+    nr = rs.normal(size=(len(q), 3)).astype(np.float32)
+    nr[: len(run)] = (0, 1, 0)
+    for radius, k in ((0.0, 100), (1.0, 100), (0.0, 300), (25.0, 50)):
+        a = g.IrradianceEst(q, nr, radius, k).astype(np.float64)
+        b = o.gather(q.astype(np.float64), nr.astype(np.float64), radius, k)
+        close = np.isclose(a, b, rtol=2e-4, atol=1e-9).all(1)
+        assert close.mean() > 0.999, (radius, k, close.mean())
+        scale = np.abs(b).max(1) + 1e-12
+        assert (np.abs(a - b).max(1) / scale)[~close].max(initial=0) < 0.5
+
