@@ -35,7 +35,11 @@
 #define PI_F 3.14159265358979323846f
 
 // ---- photon record in HBM (leaf-bucket order, 0-based; 28 B per photon) --------------------
-//   pos3[3i] = x, y, z           what the search reads: a leaf bucket is 64 x 12 B, contiguous
+// Bucket j holds photons [j n >> depth, (j + 1) n >> depth) of the sorted order, 33..64 of them, in SLOTS 64 j .. 64 j + 63
+// (round 3: until then the buckets lay back to back and every leaf step worked out its bucket's bounds with two 64-bit
+// scalar products before it could ask for the photons — 9 % of the gather); the slots beyond a bucket's photons hold NaN
+// positions, which no bound accepts.
+//   pos3[3i] = x, y, z           what the search reads: a leaf bucket is 64 x 12 B = six whole cache lines
 //   pwb[i]   = (r, g, b, bits)   what an accepted photon adds: power (already scaled by
 //                                1000/max) and direction bytes, bits = theta << 8 | phi << 16
 //   boxes[i], boxes[n_boxes+i]  min / max corners of the 64-ary tree's node boxes (see build_tree_device)
@@ -44,11 +48,12 @@
 struct grt_pmap {
   int n = 0, max = 0, device = 0, depth = 0, levels = 1, b0 = 0, n_boxes = 0;
   uint64_t emitted = 0;
-  float* d_pos3 = nullptr;   // [3(n+1)]
-  float4* d_pwb = nullptr;   // [n+1]
+  size_t slots = 0;          // 64 << depth
+  float* d_pos3 = nullptr;   // [3(slots+1)]
+  float4* d_pwb = nullptr;   // [slots+1]
   float4* d_boxes = nullptr; // [2 * n_boxes]
   float* d_lut = nullptr;    // [4*256] costheta, sintheta, cosphi, sinphi (photon_mapping.go:105-111)
-  int* d_order = nullptr;    // [n+1] slot -> storage (emission) index (grt_photon_read)
+  int* d_order = nullptr;    // [n+1] sorted position -> storage (emission) index (grt_photon_read)
   float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};  // bounds of the stored photons
 };
 
@@ -314,13 +319,18 @@ __global__ __launch_bounds__(256) void k_kd_finalize(const float4* __restrict__ 
   if (leaf >= (1 << depth)) return;
   const int a = (int)(((long long)leaf * n) >> depth), b = (int)(((long long)(leaf + 1) * n) >> depth);
   const int p = a + lane;
+  const size_t slot = (size_t)leaf * KD_LEAF + (size_t)lane;
   float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};  // an empty bucket is never within any bound
   if (p < b) {
     const int src = perm[p];
     const float4 q = pos[src], w = pow[src];
-    pos3[3 * (size_t)p] = q.x, pos3[3 * (size_t)p + 1] = q.y, pos3[3 * (size_t)p + 2] = q.z;
-    pwb[p] = make_float4(w.x, w.y, w.z, q.w);
+    pos3[3 * slot] = q.x, pos3[3 * slot + 1] = q.y, pos3[3 * slot + 2] = q.z;
+    pwb[slot] = make_float4(w.x, w.y, w.z, q.w);
     lo[0] = hi[0] = q.x, lo[1] = hi[1] = q.y, lo[2] = hi[2] = q.z;
+  } else {  // a slot beyond the bucket's photons: no distance to a NaN position is <= any bound
+    const float nan = __int_as_float(0x7fc00000);
+    pos3[3 * slot] = nan, pos3[3 * slot + 1] = nan, pos3[3 * slot + 2] = nan;
+    pwb[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -358,11 +368,15 @@ __global__ __launch_bounds__(256) void k_kd_upbox(const float4* __restrict__ chi
 }
 
 // d_pos[i] = (x, y, z, bits), d_pow[i] = (r, g, b, -) for the n photons in storage order (device).
-#define GRT_PMAP_MAX_PHOTONS 350000000  // k_gather_knn addresses a photon's 12-byte position with a 32-bit byte offset
+#define GRT_PMAP_MAX_SLOTS 350000000  // k_gather_knn addresses a photon's 12-byte position with a 32-bit byte offset
 static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, grt_pmap* pm) {
-  if (n > GRT_PMAP_MAX_PHOTONS) return grt_fail(GRT_ELIMIT, "photon map of %d photons; at most %d", n, GRT_PMAP_MAX_PHOTONS);
   int depth = 0;
   while (((long long)KD_LEAF << depth) < n) depth++;
+  const size_t slots = (size_t)KD_LEAF << depth;  // n <= slots < 2 n
+  if (slots > GRT_PMAP_MAX_SLOTS)
+    return grt_fail(GRT_ELIMIT, "photon map of %d photons takes %zu bucket slots; at most %d (2^28 = 268 435 456 photons always fit)", n, slots,
+                    GRT_PMAP_MAX_SLOTS);
+  pm->slots = slots;
   const int levels = std::max(1, (depth + KD_FAN_BITS - 1) / KD_FAN_BITS);
   const int b0 = depth - KD_FAN_BITS * (levels - 1);
   std::vector<size_t> off(levels);
@@ -375,8 +389,8 @@ static int build_tree_device(const float4* d_pos, const float4* d_pow, int n, gr
     lut[i] = (float)cos(angle), lut[256 + i] = (float)sin(angle);
     lut[512 + i] = (float)cos(2.0 * angle), lut[768 + i] = (float)sin(2.0 * angle);
   }
-  GRT_HIP(hipMalloc(&pm->d_pos3, 3 * ((size_t)n + 1) * sizeof(float)));
-  GRT_HIP(hipMalloc(&pm->d_pwb, ((size_t)n + 1) * sizeof(float4)));
+  GRT_HIP(hipMalloc(&pm->d_pos3, 3 * (slots + 1) * sizeof(float)));
+  GRT_HIP(hipMalloc(&pm->d_pwb, (slots + 1) * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_lut, lut.size() * sizeof(float)));
   GRT_HIP(hipMalloc(&pm->d_boxes, 2 * total * sizeof(float4)));
   GRT_HIP(hipMalloc(&pm->d_order, ((size_t)n + 1) * sizeof(int)));
@@ -703,14 +717,17 @@ GRT_API int grt_photon_read(const grt_pmap* pm, float* pos, float* power, uint8_
   DeviceGuard guard;
   GRT_HIP(hipSetDevice(pm->device));
   const size_t n = (size_t)pm->n;
-  std::vector<float> p3(3 * (n + 1));
-  std::vector<float4> w4(n + 1);
+  if (n == 0) return GRT_OK;
+  std::vector<float> p3(3 * pm->slots);
+  std::vector<float4> w4(pm->slots);
   GRT_HIP(hipMemcpy(p3.data(), pm->d_pos3, p3.size() * sizeof(float), hipMemcpyDeviceToHost));
   GRT_HIP(hipMemcpy(w4.data(), pm->d_pwb, w4.size() * sizeof(float4), hipMemcpyDeviceToHost));
   std::vector<int> order(n + 1);
   GRT_HIP(hipMemcpy(order.data(), pm->d_order, order.size() * sizeof(int), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) {  // back to storage (emission) order
-    const size_t d = (size_t)order[i];
+  for (size_t p = 0; p < n; ++p) {  // back to storage (emission) order: sorted position p lies in slot 64 leaf + (p - leaf's first)
+    const size_t d = (size_t)order[p];
+    const long long leaf = ((((long long)p + 1) << pm->depth) - 1) / (long long)n;  // kd_leaf_of
+    const size_t i = (size_t)leaf * KD_LEAF + (p - (size_t)leaf_start(leaf, pm->n, pm->depth));
     int bits;
     memcpy(&bits, &w4[i].w, 4);
     if (pos) pos[3 * d] = p3[3 * i], pos[3 * d + 1] = p3[3 * i + 1], pos[3 * d + 2] = p3[3 * i + 2];
@@ -984,18 +1001,13 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) __attribute__((amdgpu_num_sgpr(8
     };
     // one leaf bucket: photons within bnd go to the pool
     auto append_leaf = [&](int leaf, float bnd) {
-      // bucket [a, b) = [leaf n >> depth, (leaf + 1) n >> depth): unsigned 64-bit products (mul_hi + mul_lo + shift; the
-      // signed form cost 15 scalar instructions per bucket); the lanes beyond the bucket's 33..64 photons as a scalar mask
-      const uint32_t a = (uint32_t)(((unsigned long long)(uint32_t)leaf * (unsigned long long)(uint32_t)T.n) >> T.depth);
-      const uint32_t b = (uint32_t)(((unsigned long long)((uint32_t)leaf + 1u) * (unsigned long long)(uint32_t)T.n) >> T.depth);
-      const uint32_t cnt = b - a;  // <= 64
-      const unsigned long long vmask = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
-      const uint32_t i = a + min((uint32_t)lane, cnt - 1u);  // lanes beyond the bucket re-read its last photon
-      // 32-bit byte offset from the scalar base (photon maps hold < 2^31 / 12 photons: checked when the map is built)
-      const P3 p = *(const P3*)((const char*)T.pos3 + 12u * i);  // one 12-byte load per lane
+      // bucket `leaf` = slots 64 leaf .. 64 leaf + 63 (the slots beyond its photons hold NaN: never within a bound)
+      const uint32_t i = ((uint32_t)leaf << 6) + (uint32_t)lane;
+      // 32-bit byte offset from the scalar base (12 x slots < 2^32: checked when the map is built)
+      const P3 p = *(const P3*)((const char*)T.pos3 + 12u * i);  // one 12-byte load per lane, six whole lines per bucket
       const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
       const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(d2 <= bnd) & vmask;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(d2 <= bnd);
       const int slot = count + mbcnt64(m);
       if ((m >> lane) & 1ull) {
         pd2[slot] = d2;

@@ -7,12 +7,13 @@ CHILD = r"""
 import importlib, os, runpy, sys
 sys.path.insert(0, os.getcwd())
 importlib.import_module("go-raytracer_amd._capi").LIB_PATH = sys.argv[1]
-sys.argv = ["bench_photon.py", "--cpu-queries", "0", "--rounds", "7", "--render-spp", "0", "--only", "global"]
+sys.argv = ["bench_photon.py", "--cpu-queries", "0", "--rounds", "7", "--render-spp", "0", "--only", "global"] + sys.argv[2:]
 runpy.run_path("tools/bench_photon.py", run_name="__main__")
 """
 import json
-for lib in sys.argv[1:]:
-    r = subprocess.run([sys.executable, "-c", CHILD, lib], capture_output=True, text=True)
+extra = [a for a in sys.argv[1:] if a.startswith("--") or a.isdigit()]
+for lib in [a for a in sys.argv[1:] if a not in extra]:
+    r = subprocess.run([sys.executable, "-c", CHILD, lib] + extra, capture_output=True, text=True)
     if r.returncode != 0:
         sys.exit(r.stderr[-2000:])
     d = json.loads(r.stdout.strip().splitlines()[-1])
