@@ -218,7 +218,9 @@ int grt_primary_sweep_dev(grt_scene* scene, const grt_opts* opts, int32_t sample
  * (photon_mapping.go:197-209): emits photons from every light until max_photons are
  * stored, caustics != 0 selects the caustic filter (scene.go:359-363,375) and power
  * (1,1,1) instead of (15,15,15).  Builds the balanced bucket kd-tree (kdtree.New(list, true),
- * photon_mapping.go:207) and stages it with the photons in HBM. */
+ * photon_mapping.go:207) and stages it with the photons in HBM.  Every leaf bucket of the tree takes 64 photon slots (between n
+ * and 2 n slots of 28 bytes for n photons); a map of more than 350 000 000 slots is refused with GRT_ELIMIT (2^28 photons
+ * always fit), here and in grt_photon_load / grt_photon_load_dev. */
 int grt_photon_build(grt_scene* scene, const grt_opts* opts, int32_t max_photons, int32_t caustics,
                      grt_pmap** out);
 int32_t grt_photon_count(const grt_pmap* pmap);
